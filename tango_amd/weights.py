@@ -1,0 +1,230 @@
+"""Parameter inventories (reference state-dict key names + shapes) and seeded synthetic weights.
+
+The engine ingests exactly the tensors the reference checkpoints carry:
+  * `pytorch_model_main.bin`  -> keys `unet.*`           (AudioDiffusion.state_dict, tango.py:24,28)
+  * `pytorch_model_vae.bin`   -> keys `post_quant_conv.* decoder.* vocoder.*` (+ unused encoder.*)
+Key patterns: SURVEY.md Appendix B; module construction order follows the fork's
+UNet2DConditionModel (mustango/diffusers/src/diffusers/models/unet_2d_condition.py:116-330),
+audioldm Decoder (audioldm/variational_autoencoder/modules.py:546-648) and HiFi-GAN Generator
+(audioldm/hifigan/models.py:112-147).
+
+No real checkpoint is reachable offline, so benchmarks and parity tests use *seeded synthetic*
+weights: every tensor is drawn from its own generator keyed by (seed, crc32(name)), so the CPU
+oracle and the HIP engine can materialise identical tensors independently, one at a time.
+"""
+import zlib
+from collections import OrderedDict
+from typing import Dict, Iterator, Tuple
+
+import torch
+
+Shapes = "OrderedDict[str, Tuple[int, ...]]"
+
+
+def _resnet(out, p, cin, cout, temb):
+    out[p + ".norm1.weight"] = (cin,)
+    out[p + ".norm1.bias"] = (cin,)
+    out[p + ".conv1.weight"] = (cout, cin, 3, 3)
+    out[p + ".conv1.bias"] = (cout,)
+    out[p + ".time_emb_proj.weight"] = (cout, temb)
+    out[p + ".time_emb_proj.bias"] = (cout,)
+    out[p + ".norm2.weight"] = (cout,)
+    out[p + ".norm2.bias"] = (cout,)
+    out[p + ".conv2.weight"] = (cout, cout, 3, 3)
+    out[p + ".conv2.bias"] = (cout,)
+    if cin != cout:
+        out[p + ".conv_shortcut.weight"] = (cout, cin, 1, 1)
+        out[p + ".conv_shortcut.bias"] = (cout,)
+
+
+def _transformer(out, p, c, cross):
+    out[p + ".norm.weight"] = (c,)
+    out[p + ".norm.bias"] = (c,)
+    out[p + ".proj_in.weight"] = (c, c)
+    out[p + ".proj_in.bias"] = (c,)
+    b = p + ".transformer_blocks.0"
+    out[b + ".attn1.to_q.weight"] = (c, c)
+    out[b + ".attn1.to_k.weight"] = (c, c)
+    out[b + ".attn1.to_v.weight"] = (c, c)
+    out[b + ".attn1.to_out.0.weight"] = (c, c)
+    out[b + ".attn1.to_out.0.bias"] = (c,)
+    out[b + ".ff.net.0.proj.weight"] = (8 * c, c)
+    out[b + ".ff.net.0.proj.bias"] = (8 * c,)
+    out[b + ".ff.net.2.weight"] = (c, 4 * c)
+    out[b + ".ff.net.2.bias"] = (c,)
+    out[b + ".attn2.to_q.weight"] = (c, c)
+    out[b + ".attn2.to_k.weight"] = (c, cross)
+    out[b + ".attn2.to_v.weight"] = (c, cross)
+    out[b + ".attn2.to_out.0.weight"] = (c, c)
+    out[b + ".attn2.to_out.0.bias"] = (c,)
+    for n in ("norm1", "norm2", "norm3"):
+        out[b + "." + n + ".weight"] = (c,)
+        out[b + "." + n + ".bias"] = (c,)
+    out[p + ".proj_out.weight"] = (c, c)
+    out[p + ".proj_out.bias"] = (c,)
+
+
+def unet_param_shapes(cfg: dict, prefix: str = "") -> Shapes:
+    """All UNet tensors for a Tango-style config (686 tensors for configs/diffusion_model_config.json)."""
+    ch = list(cfg["block_out_channels"])
+    cross = cfg["cross_attention_dim"]
+    lpb = cfg.get("layers_per_block", 2)
+    temb = ch[0] * 4
+    out: Shapes = OrderedDict()
+    P = prefix
+    out[P + "conv_in.weight"] = (ch[0], cfg["in_channels"], 3, 3)
+    out[P + "conv_in.bias"] = (ch[0],)
+    out[P + "time_embedding.linear_1.weight"] = (temb, ch[0])
+    out[P + "time_embedding.linear_1.bias"] = (temb,)
+    out[P + "time_embedding.linear_2.weight"] = (temb, temb)
+    out[P + "time_embedding.linear_2.bias"] = (temb,)
+    c_prev = ch[0]
+    for i, bt in enumerate(cfg["down_block_types"]):
+        for j in range(lpb):
+            cin = c_prev if j == 0 else ch[i]
+            _resnet(out, f"{P}down_blocks.{i}.resnets.{j}", cin, ch[i], temb)
+            if bt == "CrossAttnDownBlock2D":
+                _transformer(out, f"{P}down_blocks.{i}.attentions.{j}", ch[i], cross)
+        if i != len(ch) - 1:
+            out[f"{P}down_blocks.{i}.downsamplers.0.conv.weight"] = (ch[i], ch[i], 3, 3)
+            out[f"{P}down_blocks.{i}.downsamplers.0.conv.bias"] = (ch[i],)
+        c_prev = ch[i]
+    cm = ch[-1]
+    _resnet(out, P + "mid_block.resnets.0", cm, cm, temb)
+    _transformer(out, P + "mid_block.attentions.0", cm, cross)
+    _resnet(out, P + "mid_block.resnets.1", cm, cm, temb)
+    rch = list(reversed(ch))
+    prev_out = rch[0]
+    for i, bt in enumerate(cfg["up_block_types"]):
+        outc = rch[i]
+        inc = rch[min(i + 1, len(ch) - 1)]
+        for j in range(lpb + 1):
+            skip = inc if j == lpb else outc
+            rin = prev_out if j == 0 else outc
+            _resnet(out, f"{P}up_blocks.{i}.resnets.{j}", rin + skip, outc, temb)
+            if bt == "CrossAttnUpBlock2D":
+                _transformer(out, f"{P}up_blocks.{i}.attentions.{j}", outc, cross)
+        if i != len(ch) - 1:
+            out[f"{P}up_blocks.{i}.upsamplers.0.conv.weight"] = (outc, outc, 3, 3)
+            out[f"{P}up_blocks.{i}.upsamplers.0.conv.bias"] = (outc,)
+        prev_out = outc
+    out[P + "conv_norm_out.weight"] = (ch[0],)
+    out[P + "conv_norm_out.bias"] = (ch[0],)
+    out[P + "conv_out.weight"] = (cfg["out_channels"], ch[0], 3, 3)
+    out[P + "conv_out.bias"] = (cfg["out_channels"],)
+    return out
+
+
+def _vae_res(out, p, cin, cout):
+    out[p + ".norm1.weight"] = (cin,)
+    out[p + ".norm1.bias"] = (cin,)
+    out[p + ".conv1.weight"] = (cout, cin, 3, 3)
+    out[p + ".conv1.bias"] = (cout,)
+    out[p + ".norm2.weight"] = (cout,)
+    out[p + ".norm2.bias"] = (cout,)
+    out[p + ".conv2.weight"] = (cout, cout, 3, 3)
+    out[p + ".conv2.bias"] = (cout,)
+    if cin != cout:
+        out[p + ".nin_shortcut.weight"] = (cout, cin, 1, 1)
+        out[p + ".nin_shortcut.bias"] = (cout,)
+
+
+def vae_decoder_param_shapes(cfg: dict, prefix: str = "") -> Shapes:
+    """post_quant_conv + decoder.* (the decode-side subset of pytorch_model_vae.bin)."""
+    ch, mult, nrb = cfg["ch"], list(cfg["ch_mult"]), cfg["num_res_blocks"]
+    zc, ed = cfg["z_channels"], cfg.get("embed_dim", 8)
+    out: Shapes = OrderedDict()
+    P = prefix
+    out[P + "post_quant_conv.weight"] = (zc, ed, 1, 1)
+    out[P + "post_quant_conv.bias"] = (zc,)
+    D = P + "decoder."
+    bi = ch * mult[-1]
+    out[D + "conv_in.weight"] = (bi, zc, 3, 3)
+    out[D + "conv_in.bias"] = (bi,)
+    _vae_res(out, D + "mid.block_1", bi, bi)
+    a = D + "mid.attn_1"
+    out[a + ".norm.weight"] = (bi,)
+    out[a + ".norm.bias"] = (bi,)
+    for n in ("q", "k", "v", "proj_out"):
+        out[f"{a}.{n}.weight"] = (bi, bi, 1, 1)
+        out[f"{a}.{n}.bias"] = (bi,)
+    _vae_res(out, D + "mid.block_2", bi, bi)
+    for lvl in reversed(range(len(mult))):
+        bo = ch * mult[lvl]
+        for b in range(nrb + 1):
+            _vae_res(out, f"{D}up.{lvl}.block.{b}", bi, bo)
+            bi = bo
+        if lvl != 0:
+            out[f"{D}up.{lvl}.upsample.conv.weight"] = (bi, bi, 3, 3)
+            out[f"{D}up.{lvl}.upsample.conv.bias"] = (bi,)
+    out[D + "norm_out.weight"] = (bi,)
+    out[D + "norm_out.bias"] = (bi,)
+    out[D + "conv_out.weight"] = (cfg["out_ch"], bi, 3, 3)
+    out[D + "conv_out.bias"] = (cfg["out_ch"],)
+    return out
+
+
+def hifigan_param_shapes(cfg: dict, prefix: str = "vocoder.") -> Shapes:
+    """vocoder.* of pytorch_model_vae.bin (weight-norm removed, hifigan/utilities.py:67-73)."""
+    c0 = cfg["upsample_initial_channel"]
+    out: Shapes = OrderedDict()
+    P = prefix
+    out[P + "conv_pre.weight"] = (c0, cfg["num_mels"], 7)
+    out[P + "conv_pre.bias"] = (c0,)
+    nk = len(cfg["resblock_kernel_sizes"])
+    ch = c0
+    for i, (u, k) in enumerate(zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"])):
+        out[f"{P}ups.{i}.weight"] = (c0 // 2 ** i, c0 // 2 ** (i + 1), k)   # ConvTranspose1d [in,out,k]
+        out[f"{P}ups.{i}.bias"] = (c0 // 2 ** (i + 1),)
+    for i in range(len(cfg["upsample_rates"])):
+        ch = c0 // 2 ** (i + 1)
+        for j, ks in enumerate(cfg["resblock_kernel_sizes"]):
+            rp = f"{P}resblocks.{i * nk + j}"
+            for m in range(len(cfg["resblock_dilation_sizes"][j])):
+                out[f"{rp}.convs1.{m}.weight"] = (ch, ch, ks)
+                out[f"{rp}.convs1.{m}.bias"] = (ch,)
+            for m in range(len(cfg["resblock_dilation_sizes"][j])):
+                out[f"{rp}.convs2.{m}.weight"] = (ch, ch, ks)
+                out[f"{rp}.convs2.{m}.bias"] = (ch,)
+    out[P + "conv_post.weight"] = (1, ch, 7)
+    out[P + "conv_post.bias"] = (1,)
+    return out
+
+
+def _is_norm(name: str) -> bool:
+    leaf = name.rsplit(".", 2)[-2] if name.count(".") >= 1 else name
+    return leaf.startswith("norm") or leaf in ("conv_norm_out", "norm_out")
+
+
+def synth_tensor(name: str, shape: Tuple[int, ...], seed: int = 1234) -> torch.Tensor:
+    """One seeded synthetic fp32 CPU tensor.  Matrices/filters ~ U(-b, b), b = gain/sqrt(fan_in)
+    (PyTorch's default Linear/Conv bound, gain 1; vocoder filters use gain sqrt(3) so the waveform
+    keeps a usable amplitude through the leaky-relu stack); norm gains ~ 1 + 0.1 N(0,1), norm biases
+    and layer biases ~ 0.1-scaled so that every gamma/beta/bias path is exercised by parity tests."""
+    g = torch.Generator()
+    g.manual_seed((int(seed) * 1000003 + zlib.crc32(name.encode())) % (2 ** 63 - 1))
+    if _is_norm(name):
+        t = torch.randn(shape, generator=g)
+        return (1.0 + 0.1 * t) if name.endswith(".weight") else 0.1 * t
+    if len(shape) == 1:
+        return (torch.rand(shape, generator=g) * 2 - 1) * 0.05
+    if ".ups." in name and len(shape) == 3:            # ConvTranspose1d [in, out, k]: fan_in = in*k/stride-ish
+        fan_in = shape[0] * shape[2] / 4.0
+    else:
+        fan_in = 1
+        for s in shape[1:]:
+            fan_in *= s
+    gain = 1.0
+    if name.startswith("vocoder.") or ".vocoder." in name:
+        gain = 3.0 ** 0.5
+    b = gain / (fan_in ** 0.5)
+    return (torch.rand(shape, generator=g) * 2 - 1) * b
+
+
+def synth_state_dict(shapes: Shapes, seed: int = 1234) -> Dict[str, torch.Tensor]:
+    return OrderedDict((k, synth_tensor(k, s, seed)) for k, s in shapes.items())
+
+
+def iter_synth(shapes: Shapes, seed: int = 1234) -> Iterator[Tuple[str, torch.Tensor]]:
+    for k, s in shapes.items():
+        yield k, synth_tensor(k, s, seed)
