@@ -1,0 +1,159 @@
+/* tango_engine.h -- C ABI of the MI355X-native Tango text-to-audio inference engine.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference has no C plugin API:
+ * its callers are Python duck-typed call sites.  Every entry point below names the
+ * reference interface it replaces (paths relative to the reference tree):
+ *
+ *   tango_engine_denoise        AudioDiffusion.inference loop body        models.py:224-249
+ *                               + DDPMScheduler.step                       mustango/diffusers/src/diffusers/schedulers/scheduling_ddpm.py:254-349
+ *                               (+ DDIMScheduler.step                      .../scheduling_ddim.py:238-360)
+ *   tango_engine_unet_forward   UNet2DConditionModel.forward               mustango/diffusers/src/diffusers/models/unet_2d_condition.py:520-707
+ *   tango_engine_vae_decode     AutoencoderKL.decode_first_stage           audioldm/variational_autoencoder/autoencoder.py:116-124,60-64
+ *   tango_engine_vocode         AutoencoderKL.decode_to_waveform           audioldm/variational_autoencoder/autoencoder.py:66-69
+ *                               -> vocoder_infer                           audioldm/hifigan/utilities.py:76-86
+ *   tango_engine_set_weight     load_state_dict of pytorch_model_main.bin / pytorch_model_vae.bin   tango.py:22-28
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  Tensor arguments are CALLER-OWNED DEVICE
+ *     pointers (contiguous, the reference's own shapes/layouts: NCHW fp32 latents, [B,L,d] fp32
+ *     embeddings, bool masks as uint8).  The engine never frees caller memory.
+ *   - `stream` is a hipStream_t passed as void* (the caller's current stream); all work is enqueued
+ *     on it and is asynchronous unless stated.
+ *   - every function returns 0 on success, non-zero on failure; tango_last_error() returns the
+ *     message for the calling thread.  The Python shim re-raises ValueError / RuntimeError with the
+ *     reference's conditions (e.g. num_inference_steps > num_train_timesteps).
+ *   - a handle is not re-entrant; data-parallel use = one handle per GPU / process.
+ */
+#ifndef TANGO_ENGINE_H
+#define TANGO_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TANGO_DTYPE_F32 0
+#define TANGO_DTYPE_F16 1
+#define TANGO_DTYPE_BF16 2
+
+#define TANGO_PRED_EPSILON 0
+#define TANGO_PRED_SAMPLE 1
+#define TANGO_PRED_V 2
+
+#define TANGO_RULE_DDPM 0
+#define TANGO_RULE_DDIM 1
+
+#define TANGO_MAX_LEVELS 8
+
+typedef struct tango_engine tango_engine_t;
+
+/* Mirrors configs/diffusion_model_config.json + mustango/configs/vae_config.json (ddconfig) +
+ * HIFIGAN_16K_64 (audioldm/hifigan/utilities.py:9-39).  A component with n_levels == 0 / n_ups == 0
+ * is not built. */
+typedef struct tango_config {
+  int32_t dtype;                              /* TANGO_DTYPE_*: storage/MFMA operand type; accumulation & statistics are fp32 */
+  /* UNet2DConditionModel */
+  int32_t unet_levels;                        /* len(block_out_channels) */
+  int32_t unet_channels[TANGO_MAX_LEVELS];    /* block_out_channels */
+  int32_t unet_heads[TANGO_MAX_LEVELS];       /* "attention_head_dim" (= head COUNT; head_dim is 64) */
+  int32_t unet_cross_attn[TANGO_MAX_LEVELS];  /* 1 if down block i is CrossAttnDownBlock2D */
+  int32_t unet_layers_per_block;
+  int32_t unet_in_channels, unet_out_channels;
+  int32_t unet_cross_dim;                     /* cross_attention_dim (1024 FLAN-T5-large, 2048 XL) */
+  int32_t unet_groups;                        /* norm_num_groups */
+  float unet_eps;                             /* norm_eps */
+  int32_t unet_flip_sin_to_cos;
+  float unet_freq_shift;
+  int32_t latent_h, latent_w;                 /* 256, 16 (models.py:259-260) */
+  /* mel-VAE decoder */
+  int32_t vae_levels;                         /* len(ch_mult) */
+  int32_t vae_ch;
+  int32_t vae_ch_mult[TANGO_MAX_LEVELS];
+  int32_t vae_num_res_blocks;
+  int32_t vae_z_channels, vae_embed_dim, vae_out_ch;
+  float vae_scale_factor;
+  /* HiFi-GAN */
+  int32_t voc_n_ups;
+  int32_t voc_rates[TANGO_MAX_LEVELS];
+  int32_t voc_kernels[TANGO_MAX_LEVELS];
+  int32_t voc_initial_channel;
+  int32_t voc_num_mels;
+  int32_t voc_n_resblocks;                    /* len(resblock_kernel_sizes) == 3 */
+  int32_t voc_res_kernels[4];
+  int32_t voc_res_dilations[4][4];            /* [kernel idx][pair idx]; 0-terminated rows */
+} tango_config_t;
+
+typedef struct tango_denoise_args {
+  float* latents;              /* in/out  [B, C_lat, H, W] fp32 NCHW: initial noise * init_noise_sigma in, x_0 out */
+  const float* prompt_embeds;  /* [B2, L, d] fp32, B2 = 2B ([uncond; cond], models.py:301) when cfg, else B */
+  const uint8_t* prompt_mask;  /* [B2, L] bool (1 = attend), may be NULL (no mask) */
+  int32_t batch;               /* B */
+  int32_t text_len;            /* L */
+  int32_t num_steps;           /* N */
+  const int64_t* timesteps;    /* HOST [N] (DDPMScheduler.set_timesteps, scheduling_ddpm.py:184-204) */
+  const float* coef;           /* HOST [N][8]: sqrt(abar_t), sqrt(1-abar_t), coef_x0, coef_xt, sigma, sqrt(abar_prev), dir_coef, 0 */
+  float guidance_scale;        /* CFG is on when > 1.0 (models.py:213) */
+  int32_t prediction_type;     /* TANGO_PRED_* */
+  int32_t rule;                /* TANGO_RULE_* */
+  int32_t clip_sample;
+  float clip_sample_range;
+  const float* noise;          /* device [N][B, C_lat, H, W] fp32 injected step noise (parity mode) or NULL -> device Philox */
+  uint64_t seed;               /* Philox key when noise == NULL */
+  int32_t sample_offset;       /* global index of local sample 0 (keeps Philox noise independent of the DP sharding) */
+  int32_t use_graph;           /* 1: replay the captured hipGraph of the UNet step; 0: eager launches */
+} tango_denoise_args_t;
+
+const char* tango_last_error(void);
+const char* tango_version(void);
+
+int tango_engine_create(const tango_config_t* cfg, tango_engine_t** out);
+void tango_engine_destroy(tango_engine_t* h);
+
+/* number of parameter tensors the engine expects / name of the i-th one (reference state_dict keys,
+ * "unet." prefix for the UNet as in pytorch_model_main.bin, plain keys for pytorch_model_vae.bin). */
+int tango_engine_num_weights(tango_engine_t* h);
+const char* tango_engine_weight_name(tango_engine_t* h, int i);
+/* fp32 DEVICE tensor in the reference layout (Conv OIHW, Linear [out,in], ConvTranspose1d [in,out,k]);
+ * the engine packs its own copy. `shape`/`ndim` are validated. */
+int tango_engine_set_weight(tango_engine_t* h, const char* name, const float* dev_ptr, const int64_t* shape, int ndim);
+/* fails (listing the first missing key) unless every expected tensor has been set */
+int tango_engine_finalize_weights(tango_engine_t* h);
+
+int tango_engine_denoise(tango_engine_t* h, const tango_denoise_args_t* args, void* stream);
+
+/* one UNet call: sample [B2,C,H,W] fp32 NCHW, timestep, embeds [B2,L,d], mask [B2,L] -> out [B2,C,H,W] fp32 */
+int tango_engine_unet_forward(tango_engine_t* h, const float* sample, int64_t timestep, const float* prompt_embeds,
+                              const uint8_t* prompt_mask, float* out, int batch2, int text_len, void* stream);
+
+/* latents [B,8,256,16] fp32 -> mel [B,1,1024,64] fp32 */
+int tango_engine_vae_decode(tango_engine_t* h, const float* latents, float* mel, int batch, void* stream);
+/* mel [B,1,T,num_mels] fp32 -> int16 [B, samples]; returns samples per item via *n_samples (may be NULL) */
+int tango_engine_vocode(tango_engine_t* h, const float* mel, int16_t* wav, int batch, int mel_frames, int* n_samples, void* stream);
+int tango_engine_vocoder_samples(tango_engine_t* h, int mel_frames);
+
+/* timing of the last denoise call's kernels, measured with HIP events on the launch stream */
+int tango_engine_last_denoise_ms(tango_engine_t* h, float* total_ms, float* per_step_ms);
+
+/* ---- per-operator entry points (parity tests; fp32 reference-layout tensors on device) ---- */
+int tango_op_conv2d(int dtype, const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
+                    int Cout, int stride, int upsample, void* stream);
+int tango_op_linear(int dtype, const float* x, const float* w, const float* bias, const float* residual, float* out, int M,
+                    int N, int K, int a_act, int e_act, int geglu, void* stream);
+int tango_op_conv1d(int dtype, const float* x, const float* w, const float* bias, const float* residual, float* out, int B,
+                    int Cin, int L, int Cout, int k, int dilation, int a_act, float a_slope, int e_act, float e_slope, void* stream);
+int tango_op_conv_transpose1d(int dtype, const float* x, const float* w, const float* bias, float* out, int B, int Cin, int L,
+                              int Cout, int k, int stride, int padding, int a_act, float a_slope, void* stream);
+int tango_op_groupnorm(int dtype, const float* x, const float* gamma, const float* beta, float* out, int B, int C, int HW,
+                       int groups, float eps, int act, void* stream);
+int tango_op_layernorm(int dtype, const float* x, const float* gamma, const float* beta, float* out, int rows, int C, float eps,
+                       void* stream);
+int tango_op_attention(int dtype, const float* q, const float* k, const float* v, const float* bias, float* out, int B, int heads,
+                       int Sq, int Skv, float scale, void* stream);
+int tango_op_sched_step(float* latents, const float* model_out_nchw, const float* noise, const float* coef8, int B, int C, int HW,
+                        int cfg, float guidance, int pred_type, int rule, int clip, float clip_range, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TANGO_ENGINE_H */

@@ -1,0 +1,237 @@
+// Flash attention (head_dim 64) for the 32 UNet attention sites (16 self + 16 cross).
+// Reference: Attention + AttnProcessor / AttnProcessor2_0
+// (mustango/diffusers/src/diffusers/models/attention_processor.py:302-337,495-540): softmax(q k^T * d^-0.5 + bias) v
+// with the additive -10000 mask bias broadcast over heads and queries (prepare_attention_mask :263-299).
+//
+// "Swapped" formulation so nothing crosses lanes between the two matmuls:
+//   S^T = K Q^T  (MFMA A = K rows from LDS, B = Q fragments held in registers)
+//   O^T = V^T P^T (MFMA A = V^T rows from LDS, B = P^T straight from the S^T accumulators)
+// In the 16x16 accumulator layout every lane owns ONE query column (q = lane & 15) and 4 kv rows per
+// 16-kv block, so the online-softmax state (m, l, rescale) is a per-lane scalar and row reductions are
+// in-register + two cross-group shuffles.  Softmax statistics and accumulation are fp32 always.
+#include "common.h"
+
+namespace tango {
+
+template <typename T> struct AMma;
+template <> struct AMma<float> {
+  __device__ static __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc, 0, 0, 0);
+  }
+};
+template <> struct AMma<f16> {
+  __device__ static __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+  }
+};
+template <> struct AMma<bf16> {
+  __device__ static __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  }
+};
+
+template <typename T, int QB>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  constexpr int D = 64, KVT = 64;
+  constexpr int ROWB = D * (int)sizeof(T);      // bytes per K row (and per V^T row)
+  constexpr int LDSR = ROWB + 16;
+  constexpr int NKG = ROWB / 64;                // 64-byte k groups over head_dim
+  constexpr int PPR = ROWB / 16;
+  constexpr int NPASS = KVT * PPR / 256;
+  constexpr bool HALF = sizeof(T) == 2;
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KVT * LDSR];
+  unsigned char* Ks = smem;
+  unsigned char* Vt = smem + KVT * LDSR;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qbase = blockIdx.x * (64 * QB) + wave * (16 * QB);
+
+  const T* Qp = (const T*)p.q + (int64_t)b * p.Sq * p.ldq + h * D;
+  const T* Kp = (const T*)p.k + (int64_t)b * p.Skv * p.ldk + h * D;
+  const T* Vp = (const T*)p.v + (int64_t)b * p.Skv * p.ldv + h * D;
+  T* Op = (T*)p.o + (int64_t)b * p.Sq * p.ldo + h * D;
+  const float* bias = p.bias ? p.bias + (int64_t)b * p.Skv : nullptr;
+
+  u32x4 qf[QB][NKG];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int q = qbase + qb * 16 + l15;
+#pragma unroll
+    for (int ks = 0; ks < NKG; ++ks) {
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (q < p.Sq) v = *(const u32x4*)((const unsigned char*)(Qp + (int64_t)q * p.ldq) + ks * 64 + g * 16);
+      qf[qb][ks] = v;
+    }
+  }
+
+  f32x4 oacc[QB][4];
+  float mrow[QB], lrow[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    mrow[qb] = -1.0e30f; lrow[qb] = 0.f;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) oacc[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  for (int kv0 = 0; kv0 < p.Skv; kv0 += KVT) {
+    // ---- stage K (row-major) and V (transposed) tiles ----
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      const int id = tid + i * 256;
+      const int row = id / PPR, pc = id % PPR;
+      const int kv = kv0 + row;
+      u32x4 kvv = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
+      if (kv < p.Skv) {
+        kvv = *(const u32x4*)((const unsigned char*)(Kp + (int64_t)kv * p.ldk) + pc * 16);
+        vv = *(const u32x4*)((const unsigned char*)(Vp + (int64_t)kv * p.ldv) + pc * 16);
+      }
+      *(u32x4*)(Ks + row * LDSR + pc * 16) = kvv;
+      T e[EPV];
+      __builtin_memcpy(e, &vv, 16);
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) *(T*)(Vt + (pc * EPV + j) * LDSR + row * (int)sizeof(T)) = e[j];
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T ----
+    f32x4 sacc[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) sacc[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int ks = 0; ks < NKG; ++ks) {
+        const u32x4 kf = *(const u32x4*)(Ks + (kb * 16 + l15) * LDSR + ks * 64 + g * 16);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) AMma<T>::run(sacc[qb][kb], kf, qf[qb][ks]);
+      }
+    }
+
+    // ---- online softmax (per lane: one q column, 16 kv values) ----
+    float bv[4][4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kv = kv0 + kb * 16 + g * 4 + r;
+        bv[kb][r] = (kv < p.Skv) ? (bias ? bias[kv] : 0.f) : -1.0e30f;
+      }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float mt = -1.0e30f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sv = sacc[qb][kb][r] * p.scale + bv[kb][r];
+          sacc[qb][kb][r] = sv;
+          mt = fmaxf(mt, sv);
+        }
+      mt = fmaxf(mt, __shfl_xor(mt, 16));
+      mt = fmaxf(mt, __shfl_xor(mt, 32));
+      const float mnew = fmaxf(mrow[qb], mt);
+      const float alpha = __expf(mrow[qb] - mnew);
+      float rs = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __expf(sacc[qb][kb][r] - mnew);
+          sacc[qb][kb][r] = pv;
+          rs += pv;
+        }
+      rs += __shfl_xor(rs, 16);
+      rs += __shfl_xor(rs, 32);
+      lrow[qb] = lrow[qb] * alpha + rs;
+      mrow[qb] = mnew;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) oacc[qb][db] *= alpha;
+    }
+
+    // ---- O^T += V^T P^T ----
+    if constexpr (HALF) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        u32x4 pf[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          T e[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { e[r] = from_f<T>(sacc[qb][2 * j][r]); e[4 + r] = from_f<T>(sacc[qb][2 * j + 1][r]); }
+          __builtin_memcpy(&pf[qb], e, 16);
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const unsigned char* vr = Vt + (db * 16 + l15) * LDSR;
+          const u32x2 lo = *(const u32x2*)(vr + ((2 * j) * 16 + g * 4) * 2);
+          const u32x2 hi = *(const u32x2*)(vr + ((2 * j + 1) * 16 + g * 4) * 2);
+          const u32x4 vf = u32x4{lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) AMma<T>::run(oacc[qb][db], vf, pf[qb]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const u32x4 vf = *(const u32x4*)(Vt + (db * 16 + l15) * LDSR + (kb * 16 + g * 4) * 4);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            const u32x4 pf = __builtin_bit_cast(u32x4, sacc[qb][kb]);
+            AMma<T>::run(oacc[qb][db], vf, pf);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane holds O[q][db*16 + g*4 + 0..3] ----
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int q = qbase + qb * 16 + l15;
+    if (q >= p.Sq) continue;
+    const float inv = 1.0f / lrow[qb];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      T e[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e[r] = from_f<T>(oacc[qb][db][r] * inv);
+      __builtin_memcpy(Op + (int64_t)q * p.ldo + db * 16 + g * 4, e, 4 * sizeof(T));
+    }
+  }
+}
+
+template <typename T>
+static int attn_launch(const AttnParams& p, hipStream_t s) {
+  if ((p.ldq * (int64_t)sizeof(T)) % 16 || (p.ldk * (int64_t)sizeof(T)) % 16 || (p.ldv * (int64_t)sizeof(T)) % 16 ||
+      (p.ldo * (int64_t)sizeof(T)) % 8)
+    TANGO_FAIL("attention: ld alignment");
+  constexpr int QB = 2;
+  dim3 grid((unsigned)((p.Sq + 64 * QB - 1) / (64 * QB)), (unsigned)p.heads, (unsigned)p.B);
+  hipLaunchKernelGGL((attn_kernel<T, QB>), grid, dim3(256), 0, s, p);
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_attention(int dtype, const AttnParams& p, hipStream_t s) {
+  switch (dtype) {
+    case DT_F32: return attn_launch<float>(p, s);
+    case DT_F16: return attn_launch<f16>(p, s);
+    case DT_BF16: return attn_launch<bf16>(p, s);
+  }
+  TANGO_FAIL("attention: bad dtype");
+}
+
+}  // namespace tango

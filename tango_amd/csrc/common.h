@@ -1,0 +1,203 @@
+// Common types for the Tango MI355X engine (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace tango {
+
+enum DType : int { DT_F32 = 0, DT_F16 = 1, DT_BF16 = 2 };
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+
+template <typename T> struct TypeTag;
+template <> struct TypeTag<float> { static constexpr int dt = DT_F32; };
+template <> struct TypeTag<f16> { static constexpr int dt = DT_F16; };
+template <> struct TypeTag<bf16> { static constexpr int dt = DT_BF16; };
+
+// ---- error plumbing (C ABI returns int, message via tango_last_error) ----
+void set_error(const std::string& msg);
+#define TANGO_HIP(expr)                                                                        \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      ::tango::set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " at " +   \
+                         __FILE__ + ":" + std::to_string(__LINE__));                           \
+      return -1;                                                                               \
+    }                                                                                          \
+  } while (0)
+#define TANGO_FAIL(msg)                                                                        \
+  do {                                                                                         \
+    ::tango::set_error(std::string(msg) + " at " + __FILE__ + ":" + std::to_string(__LINE__)); \
+    return -1;                                                                                 \
+  } while (0)
+#define TANGO_TRY(expr)       \
+  do {                        \
+    int _r = (expr);          \
+    if (_r != 0) return _r;   \
+  } while (0)
+
+// ---- device helpers ----
+template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v) { return (T)v; }
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// activation codes shared by prologues / epilogues
+enum Act : int { ACT_NONE = 0, ACT_SILU = 1, ACT_LRELU = 2, ACT_GELU = 3, ACT_TANH = 4 };
+
+__device__ __forceinline__ float apply_act(float x, int act, float slope) {
+  switch (act) {
+    case ACT_SILU: return silu_f(x);
+    case ACT_LRELU: return x > 0.f ? x : x * slope;
+    case ACT_GELU: return gelu_erf_f(x);
+    case ACT_TANH: return tanhf(x);
+    default: return x;
+  }
+}
+
+// A (rows x C) activation view in HBM: element type is the engine dtype, row stride `ld` elements.
+struct View {
+  void* p = nullptr;
+  int64_t ld = 0;
+  int C = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// Gather-GEMM: out[orow(m), n] = epi( alpha * sum_k A_gather[m, k] * W[n, k] + bias[n] ... )
+// The A operand is gathered on the fly (implicit GEMM): linear rows, 3x3 conv2d taps on NHWC
+// (stride 1/2, optional fused nearest-2x upsample of the source), or conv1d / transposed-conv1d
+// phase taps on channels-last [B, L, C].  K = taps * Cin, tap-major, Cin % BK == 0.
+// ------------------------------------------------------------------------------------------
+enum GatherMode : int { GATHER_1D = 0, GATHER_2D = 1 };
+enum Epi : int { EPI_NONE = 0, EPI_GEGLU = 1, EPI_I16 = 2 };
+
+struct GemmParams {
+  const void* A = nullptr;   // T
+  const void* W = nullptr;   // T  [N][Kp], K contiguous
+  const float* bias = nullptr;      // [N] (or [M-rows] when bias_rows)
+  const float* bias2 = nullptr;     // [bias2_stride * steps][N]: per-step bias (time embedding)
+  const int* step_ptr = nullptr;    // device step counter used to index bias2
+  int bias2_stride = 0;
+  const void* R = nullptr;   // residual T, indexed like out
+  int64_t ldr = 0;
+  void* out = nullptr;       // T, or float when out_f32, or int16 when epi == EPI_I16
+  int64_t ldo = 0;
+  int out_f32 = 0;
+  int M = 0, N = 0, K = 0, Cin = 0;
+  int64_t Kp = 0;            // W row stride
+  int64_t lda = 0;
+  int mode = GATHER_1D;
+  // 2D: output grid H x W per image; source image Hin x Win (conv input is source upsampled if ups)
+  int H = 0, Wd = 0, Hin = 0, Win = 0, stride = 1, ups = 0;
+  // 1D: rows_pb output rows per batch item; source length Lin; index = q*in_mul + in_off + tap*tap_step
+  int rows_pb = 0, Lin = 0, taps = 1, tap_step = 1, in_off = 0, in_mul = 1;
+  int Lout = 0, out_mul = 1, out_off = 0;  // out row = b*Lout + q*out_mul + out_off
+  int a_act = ACT_NONE;      // prologue on A
+  float a_slope = 0.f;
+  int epi = EPI_NONE;
+  int e_act = ACT_NONE;      // epilogue activation (after bias, before residual)
+  float e_slope = 0.f;
+  float alpha = 1.f;
+  float out_scale = 1.f;     // applied last (EPI_I16: 32768)
+  int bias_rows = 0;         // bias indexed by output row instead of column
+  // batched GEMM (blockIdx.z)
+  int batch = 1;
+  int64_t sA = 0, sW = 0, sO = 0, sR = 0, sBias = 0;
+};
+
+int launch_gemm(int dtype, const GemmParams& p, hipStream_t s);
+
+// ---- norms ----
+struct GroupNormParams {
+  const void* x; int64_t ldx;     // [B*rows, C]
+  void* y; int64_t ldy;
+  const float* gamma; const float* beta;
+  int B, rows, C, groups;
+  float eps;
+  int act;                        // ACT_NONE / ACT_SILU
+  float* partial;                 // workspace: [B][chunks][groups][2]
+  float* scale_shift;             // workspace: [B][C][2]
+};
+size_t groupnorm_ws_floats(int B, int rows, int C, int groups);
+int launch_groupnorm(int dtype, const GroupNormParams& p, hipStream_t s);
+
+int launch_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma,
+                     const float* beta, int rows, int C, float eps, hipStream_t s);
+
+// ---- attention (head_dim 64) ----
+struct AttnParams {
+  const void* q; int64_t ldq;     // [B*Sq, >= heads*64]
+  const void* k; int64_t ldk;     // [B*Skv, ...]
+  const void* v; int64_t ldv;
+  void* o; int64_t ldo;
+  const float* bias;              // [B][Skv] additive or null
+  int B, heads, Sq, Skv;
+  float scale;
+};
+int launch_attention(int dtype, const AttnParams& p, hipStream_t s);
+
+// row softmax (in place) used by the VAE single-head 512-d attention: x[rows][cols] *= scale; softmax
+int launch_softmax_rows(int dtype, void* x, int64_t ld, int rows, int cols, float scale, hipStream_t s);
+
+// ---- elementwise / layout ----
+struct SchedParams {
+  float* lat;            // [B,8,256,16] fp32 NCHW, updated in place
+  const float* eps;      // UNet output fp32 NHWC [B2, HW, C] (B2 = 2B when cfg)
+  void* xin;             // next UNet input, T, NHWC [B2, HW, Cpad]
+  int xin_ld;
+  const float* noise;    // [steps][B*C*HW] or null -> philox
+  const float* coef;     // [steps][8] device
+  const int* step_ptr;
+  int B, C, HW;
+  int cfg;               // 1: eps holds [uncond; cond]
+  float guidance;
+  int pred_type;         // 0 epsilon, 1 sample, 2 v_prediction
+  int rule;              // 0 DDPM, 1 DDIM
+  int clip; float clip_range;
+  unsigned long long seed;
+  int sample_offset;     // global sample index of local sample 0 (multi-GPU invariant noise)
+};
+int launch_sched_step(int dtype, const SchedParams& p, hipStream_t s);
+int launch_step_inc(int* step_ptr, hipStream_t s);
+
+// latents fp32 NCHW [B,C,HW] -> T NHWC [rep*B, HW, ld] (replicated `rep` times along batch), zero-pads C..ld? no: writes C channels
+int launch_nchw_to_nhwc(int dtype, const float* src, void* dst, int64_t ld, int B, int C, int HW, int rep, float scale, hipStream_t s);
+// T NHWC [B,HW,ld] (first C channels) -> fp32 NCHW
+int launch_nhwc_to_nchw_f32(int dtype, const void* src, int64_t ld, float* dst, int B, int C, int HW, hipStream_t s);
+// fp32 -> T cast with row stride (embeddings): src [rows][C] contiguous
+int launch_cast_rows(int dtype, const float* src, void* dst, int64_t ld, int rows, int C, hipStream_t s);
+// im2col for tiny-Cin 3x3 convs: src T NHWC [B,H,W,(ld)] first C channels -> dst T [B*H*W][Kp], k = tap*C + c, zero padded to Kp
+int launch_im2col3x3(int dtype, const void* src, int64_t ld, void* dst, int64_t Kp, int B, int H, int W, int C, hipStream_t s);
+// y = act((a + b + c) * scale)
+int launch_avg3_act(int dtype, const void* a, const void* b, const void* c, void* y, int64_t n, float scale, int act, float slope, hipStream_t s);
+// mask bool [B][L] -> additive bias fp32 (1-m)*-10000
+int launch_mask_bias(const uint8_t* mask, float* bias, int n, hipStream_t s);
+// sinusoidal timestep embedding table: out fp32 [n][dim]; [cos|sin] when flip
+int launch_timestep_embedding(const int64_t* ts_dev, float* out, int n, int dim, int flip, float freq_shift, hipStream_t s);
+// small fp32 linear: y[r][n] = act_out( sum_k act_in(x[r][k]) * W[n][k] + b[n] ), W fp32 [N][K]
+int launch_linear_f32(const float* x, const float* W, const float* b, float* y, int rows, int N, int K, int act_in, int act_out, hipStream_t s);
+
+// ---- weight packing (fp32 source in reference layout -> T engine layout) ----
+// generic strided permute-cast: dst[o][t][i] = src[o*so + t*st + i*si], dst row stride Kp (zero pad)
+int launch_pack(int dtype, const float* src, void* dst, int O, int Tn, int I, int64_t so, int64_t st, int64_t si,
+                int64_t Kp, int64_t dst_row_off, hipStream_t s);
+int launch_fill_zero(void* p, size_t bytes, hipStream_t s);
+// lat f32 NCHW [B,Cin,HW] * scale -> 1x1 conv (W f32 [Cout][Cin], b) -> T NHWC [B*HW][ld]
+int launch_pointwise_small(int dtype, const float* src, const float* W, const float* b, void* dst, int64_t ld, int B, int Cin,
+                           int Cout, int HW, float scale, hipStream_t s);
+int launch_permute_geglu_bias(const float* src, float* dst, int n, hipStream_t s);
+
+}  // namespace tango

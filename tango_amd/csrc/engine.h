@@ -1,0 +1,219 @@
+// Internal engine classes (host side).  The public surface is include/tango_engine.h.
+#pragma once
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/tango_engine.h"
+#include "common.h"
+
+namespace tango {
+
+using Op = std::function<int(hipStream_t)>;
+
+struct Program {
+  std::vector<Op> ops;
+  int run(hipStream_t s) const {
+    for (const auto& o : ops) TANGO_TRY(o(s));
+    return 0;
+  }
+};
+
+// bump allocator over one hipMalloc'd slab; build is run twice (measure, then real)
+struct Arena {
+  char* base = nullptr;
+  size_t off = 0, peak = 0;
+  void* alloc(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    void* p = base ? (void*)(base + off) : (void*)(uintptr_t)(0x1000 + off);
+    off += bytes;
+    if (off > peak) peak = off;
+    return p;
+  }
+  size_t mark() const { return off; }
+  void release(size_t m) { off = m; }
+};
+
+struct TView {
+  void* p = nullptr;
+  int64_t ld = 0;
+  int C = 0;
+};
+
+struct WMat {            // packed GEMM weight [N][Kp] (engine dtype) + fp32 bias
+  void* W = nullptr;
+  float* b = nullptr;
+  int N = 0, K = 0, Cin = 0, taps = 1;
+  int64_t Kp = 0;
+  bool im2col = false;   // 3x3 conv with tiny Cin: K = 9*Cin zero-padded to Kp, A comes from im2col
+};
+struct WNorm {
+  float* g = nullptr;
+  float* b = nullptr;
+  int C = 0;
+  float eps = 1e-5f;
+};
+struct WLinF32 {         // fp32 [N][K] (time-embedding path stays fp32)
+  float* W = nullptr;
+  float* b = nullptr;
+  int N = 0, K = 0;
+};
+
+struct ResW {
+  int cin = 0, cout = 0;
+  WNorm n1, n2;
+  WMat c1, c2, sc;
+  bool has_sc = false;
+  bool has_temb = false;
+  WLinF32 temb;
+  float* temb_table = nullptr;  // [max_steps][cout] fp32, filled per denoise call
+};
+struct XfW {             // Transformer2DModel with one BasicTransformerBlock
+  int C = 0, heads = 0;
+  WNorm gn, ln1, ln2, ln3;
+  WMat proj_in, qkv, o1, q2, kv2, o2, ff1, ff2, proj_out;
+};
+struct VaeAttnW {
+  WNorm gn;
+  WMat qk, v, proj;
+};
+struct ConvTW {          // ConvTranspose1d decomposed into `stride` phase matrices
+  int cin = 0, cout = 0, k = 0, u = 0, pad = 0;
+  std::vector<WMat> phase;
+  float* b = nullptr;
+};
+struct VocResW {
+  int ch = 0, k = 0;
+  std::vector<int> dil;
+  std::vector<WMat> c1, c2;
+};
+
+struct Slot {
+  std::string name;
+  std::vector<int64_t> shape;
+  bool set = false;
+  std::function<int(const float*, hipStream_t)> pack;
+};
+
+struct UNetPlan {
+  int B2 = 0, L = 0;
+  char* slab = nullptr;
+  Program pre, step;
+  void* xin = nullptr;      // T  [B2*HW][8]
+  float* eps = nullptr;     // f32 [B2*HW][out_ch]
+  void* enc = nullptr;      // T  [B2*L][cross]
+  float* bias = nullptr;    // f32 [B2*L]
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+struct VaePlan {           // also used for the vocoder: plan-owned in/out staging buffers
+  int B = 0;
+  char* slab = nullptr;
+  Program prog;
+  void* in = nullptr;
+  void* out = nullptr;
+  size_t in_bytes = 0, out_bytes = 0;
+  int n_out = 0;            // vocoder: samples per item
+};
+
+class Engine {
+ public:
+  explicit Engine(const tango_config_t& c);
+  ~Engine();
+  int init();
+
+  int set_weight(const char* name, const float* dev, const int64_t* shape, int ndim);
+  int finalize_weights();
+  int denoise(const tango_denoise_args_t& a, hipStream_t s);
+  int unet_forward(const float* sample, int64_t t, const float* enc, const uint8_t* mask, float* out, int B2, int L, hipStream_t s);
+  int vae_decode(const float* lat, float* mel, int B, hipStream_t s);
+  int vocode(const float* mel, int16_t* wav, int B, int frames, int* n_samples, hipStream_t s);
+  int vocoder_samples(int frames) const;
+  int last_denoise_ms(float* total_ms, float* per_step_ms);
+
+  tango_config_t cfg;
+  int dt = DT_F32;
+  size_t esz = 4;
+  std::vector<Slot> slots;
+  std::unordered_map<std::string, int> slot_index;
+  bool finalized = false;
+  float last_total_ms = 0.f, last_step_ms = 0.f;
+
+ private:
+  friend struct Builder;
+  // ---- memory ----
+  std::vector<void*> owned;
+  void* dmalloc(size_t bytes);
+  // ---- weight registration ----
+  void reg_slot(const std::string& name, std::vector<int64_t> shape, std::function<int(const float*, hipStream_t)> pack);
+  void reg_vec(const std::string& name, int n, float** dst);
+  void reg_norm(const std::string& p, int C, float eps, WNorm& w);
+  void reg_mat(const std::string& wname, int N, int K, WMat& w, bool alloc, int row_off, std::vector<int64_t> shape, bool geglu = false);
+  void reg_linear(const std::string& p, int N, int K, WMat& w, bool bias);
+  void reg_conv3x3(const std::string& p, int Cout, int Cin, WMat& w);
+  void reg_conv1x1(const std::string& p, int Cout, int Cin, WMat& w);
+  void reg_conv1d(const std::string& p, int Cout, int Cin, int k, WMat& w);
+  void reg_convt1d(const std::string& p, int Cin, int Cout, int k, int u, ConvTW& w);
+  void reg_linear_f32(const std::string& p, int N, int K, WLinF32& w);
+  void reg_res(const std::string& p, int cin, int cout, int temb, float eps, ResW& w, bool vae);
+  void reg_xf(const std::string& p, int C, int heads, int cross, XfW& w);
+  void build_unet_weights();
+  void build_vae_weights();
+  void build_voc_weights();
+
+  // ---- model weights ----
+  // UNet
+  WMat conv_in, conv_out;
+  WNorm norm_out;
+  WLinF32 time1, time2;
+  struct DownBlock { std::vector<ResW> res; std::vector<XfW> xf; bool has_ds = false; WMat ds; };
+  struct UpBlock { std::vector<ResW> res; std::vector<XfW> xf; bool has_us = false; WMat us; };
+  std::vector<DownBlock> down;
+  std::vector<UpBlock> up;
+  ResW mid_res0, mid_res1;
+  XfW mid_xf;
+  std::vector<ResW*> all_res;   // every UNet resblock (temb tables)
+  std::vector<XfW*> all_xf;
+  // VAE
+  float* pqc_w = nullptr; float* pqc_b = nullptr;
+  WMat vae_conv_in, vae_conv_out;
+  ResW vae_mid1, vae_mid2;
+  VaeAttnW vae_attn;
+  struct VaeUp { std::vector<ResW> res; bool has_up = false; WMat up; };
+  std::vector<VaeUp> vae_up;    // indexed by level
+  WNorm vae_norm_out;
+  // vocoder
+  WMat voc_pre, voc_post;
+  std::vector<ConvTW> voc_ups;
+  std::vector<VocResW> voc_res;
+
+  // ---- runtime state ----
+  int* d_step = nullptr;
+  int64_t* d_ts = nullptr;       // [max_steps]
+  float* d_coef = nullptr;       // [max_steps][8]
+  float* d_sin = nullptr;        // [max_steps][ch0]
+  float* d_t1 = nullptr;         // [max_steps][temb]
+  float* d_temb = nullptr;       // [max_steps][temb]  silu(emb)
+  std::vector<int64_t> temb_ts;  // cache key
+  int max_steps = 1000;
+  std::map<std::pair<int, int>, std::unique_ptr<UNetPlan>> unet_plans;
+  std::map<int, std::unique_ptr<VaePlan>> vae_plans;
+  std::map<std::pair<int, int>, std::unique_ptr<VaePlan>> voc_plans;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t cap_stream = nullptr;
+  int last_steps = 0;
+
+  int ensure_temb(const int64_t* ts_host, int n, hipStream_t s);
+  int get_unet_plan(int B2, int L, UNetPlan** out);
+  int build_unet(UNetPlan& P, Arena& A, bool record);
+  int get_vae_plan(int B, VaePlan** out);
+  int build_vae(VaePlan& P, Arena& A, bool record);
+  int get_voc_plan(int B, int frames, VaePlan** out);
+  int build_voc(VaePlan& P, Arena& A, bool record, int frames);
+  int bind_text(UNetPlan& P, const float* enc, const uint8_t* mask, hipStream_t s);
+};
+
+}  // namespace tango

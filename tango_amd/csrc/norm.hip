@@ -1,0 +1,362 @@
+// GroupNorm / LayerNorm / row-softmax kernels for channels-last activations (HBM-bound).
+// Reference ops replaced: native_group_norm (61/UNet step, 24/VAE), native_layer_norm (48), softmax
+// (VAE AttnBlock, audioldm/variational_autoencoder/modules.py:204-230).
+// Statistics are always fp32; 16-byte vector loads; wave64 shuffle reductions.
+#include "common.h"
+
+namespace tango {
+
+static constexpr int GN_NV = 3;      // max 16B vectors per thread per row
+static constexpr int GN_MAXC = 4096;
+
+template <typename T> __device__ __forceinline__ void unpack16(const u32x4& v, float* f) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  T e[EPV];
+  __builtin_memcpy(e, &v, 16);
+#pragma unroll
+  for (int i = 0; i < EPV; ++i) f[i] = to_f(e[i]);
+}
+template <typename T> __device__ __forceinline__ u32x4 pack16(const float* f) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  T e[EPV];
+#pragma unroll
+  for (int i = 0; i < EPV; ++i) e[i] = from_f<T>(f[i]);
+  u32x4 v;
+  __builtin_memcpy(&v, e, 16);
+  return v;
+}
+
+struct GnGeom {
+  int VPR, TPR, RPB, RC, chunks;
+};
+
+template <typename T> static GnGeom gn_geom(int B, int rows, int C) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  GnGeom g;
+  g.VPR = C / EPV;
+  g.TPR = g.VPR < 256 ? g.VPR : 256;
+  g.RPB = 256 / g.TPR;
+  if (g.RPB < 1) g.RPB = 1;
+  long total = (long)rows * B;
+  int rc = (int)((total + 2047) / 2048);
+  if (rc < 16) rc = 16;
+  rc = ((rc + g.RPB - 1) / g.RPB) * g.RPB;
+  if (rc > rows) rc = ((rows + g.RPB - 1) / g.RPB) * g.RPB;
+  g.RC = rc;
+  g.chunks = (rows + rc - 1) / rc;
+  return g;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ partial,
+                                                       int rows, int C, int groups, int VPR, int TPR, int RPB, int RC) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  __shared__ float sm[2][GN_MAXC];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int rl = tid / TPR, tv = tid % TPR;
+  float s[GN_NV][EPV], ss[GN_NV][EPV];
+#pragma unroll
+  for (int j = 0; j < GN_NV; ++j)
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { s[j][e] = 0.f; ss[j][e] = 0.f; }
+  const int r0 = chunk * RC, r1 = min(rows, r0 + RC);
+  if (rl < RPB) {
+    for (int r = r0 + rl; r < r1; r += RPB) {
+      const T* row = x + ((int64_t)b * rows + r) * ldx;
+#pragma unroll
+      for (int j = 0; j < GN_NV; ++j) {
+        const int v = tv + j * TPR;
+        if (v < VPR) {
+          float f[EPV];
+          unpack16<T>(*(const u32x4*)(row + v * EPV), f);
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) { s[j][e] += f[e]; ss[j][e] += f[e] * f[e]; }
+        }
+      }
+    }
+  }
+  // reduce over rl through LDS (RPB*C <= 2048 when RPB > 1)
+  for (int pass = 0; pass < RPB; ++pass) {
+    if (rl == pass) {
+#pragma unroll
+      for (int j = 0; j < GN_NV; ++j) {
+        const int v = tv + j * TPR;
+        if (v < VPR) {
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) {
+            const int c = v * EPV + e;
+            if (pass == 0) { sm[0][c] = s[j][e]; sm[1][c] = ss[j][e]; }
+            else { sm[0][c] += s[j][e]; sm[1][c] += ss[j][e]; }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int cg = C / groups;
+  if (tid < groups) {
+    float a = 0.f, q = 0.f;
+    for (int c = tid * cg; c < (tid + 1) * cg; ++c) { a += sm[0][c]; q += sm[1][c]; }
+    float* o = partial + (((int64_t)b * gridDim.x + chunk) * groups + tid) * 2;
+    o[0] = a; o[1] = q;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ scale_shift,
+                                                          int chunks, int rows, int C, int groups, float eps) {
+  __shared__ float mean_s[256], rstd_s[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int cg = C / groups;
+  if (tid < groups) {
+    double a = 0.0, q = 0.0;
+    for (int ch = 0; ch < chunks; ++ch) {
+      const float* o = partial + (((int64_t)b * chunks + ch) * groups + tid) * 2;
+      a += (double)o[0]; q += (double)o[1];
+    }
+    const double n = (double)rows * cg;
+    const double mean = a / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_s[tid] = (float)mean;
+    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cg;
+    const float sc = rstd_s[g] * gamma[c];
+    scale_shift[((int64_t)b * C + c) * 2 + 0] = sc;
+    scale_shift[((int64_t)b * C + c) * 2 + 1] = beta[c] - mean_s[g] * sc;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
+                                                       const float* __restrict__ scale_shift, int rows, int C, int act,
+                                                       int VPR, int TPR, int RPB, int RC) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int rl = tid / TPR, tv = tid % TPR;
+  if (rl >= RPB) return;
+  float sc[GN_NV][EPV], sh[GN_NV][EPV];
+#pragma unroll
+  for (int j = 0; j < GN_NV; ++j) {
+    const int v = tv + j * TPR;
+    if (v < VPR) {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        const f32x2 t = *(const f32x2*)(scale_shift + ((int64_t)b * C + v * EPV + e) * 2);
+        sc[j][e] = t[0]; sh[j][e] = t[1];
+      }
+    }
+  }
+  const int r0 = chunk * RC, r1 = min(rows, r0 + RC);
+  for (int r = r0 + rl; r < r1; r += RPB) {
+    const T* row = x + ((int64_t)b * rows + r) * ldx;
+    T* orow = y + ((int64_t)b * rows + r) * ldy;
+#pragma unroll
+    for (int j = 0; j < GN_NV; ++j) {
+      const int v = tv + j * TPR;
+      if (v < VPR) {
+        float f[EPV];
+        unpack16<T>(*(const u32x4*)(row + v * EPV), f);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          float t = f[e] * sc[j][e] + sh[j][e];
+          if (act == ACT_SILU) t = silu_f(t);
+          f[e] = t;
+        }
+        *(u32x4*)(orow + v * EPV) = pack16<T>(f);
+      }
+    }
+  }
+}
+
+size_t groupnorm_ws_floats(int B, int rows, int C, int groups) {
+  // upper bound on B*chunks*groups*2 (chunks <= rows/16 + 1) + B*C*2
+  size_t chunks = (size_t)rows / 16 + 2;
+  if (chunks > 2048 + 2) chunks = 2048 + 2;
+  return (size_t)B * chunks * groups * 2 + (size_t)B * C * 2;
+}
+
+template <typename T>
+static int gn_launch(const GroupNormParams& p, hipStream_t s) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  if (p.C % EPV != 0 || p.C > GN_MAXC || p.C % p.groups != 0 || p.groups > 256) TANGO_FAIL("groupnorm: unsupported C/groups");
+  if (p.C / EPV > 256 * GN_NV) TANGO_FAIL("groupnorm: C too large");
+  if ((p.ldx * (int64_t)sizeof(T)) % 16 || (p.ldy * (int64_t)sizeof(T)) % 16) TANGO_FAIL("groupnorm: ld alignment");
+  const GnGeom g = gn_geom<T>(p.B, p.rows, p.C);
+  dim3 grid((unsigned)g.chunks, (unsigned)p.B);
+  hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(256), 0, s, (const T*)p.x, p.ldx, p.partial, p.rows, p.C, p.groups,
+                     g.VPR, g.TPR, g.RPB, g.RC);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)p.B), dim3(256), 0, s, p.partial, p.gamma, p.beta, p.scale_shift,
+                     g.chunks, p.rows, p.C, p.groups, p.eps);
+  hipLaunchKernelGGL((gn_apply_kernel<T>), grid, dim3(256), 0, s, (const T*)p.x, p.ldx, (T*)p.y, p.ldy, p.scale_shift, p.rows,
+                     p.C, p.act, g.VPR, g.TPR, g.RPB, g.RC);
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_groupnorm(int dtype, const GroupNormParams& p, hipStream_t s) {
+  switch (dtype) {
+    case DT_F32: return gn_launch<float>(p, s);
+    case DT_F16: return gn_launch<f16>(p, s);
+    case DT_BF16: return gn_launch<bf16>(p, s);
+  }
+  TANGO_FAIL("groupnorm: bad dtype");
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row held in registers, two-pass (mean, then centered variance)
+// ------------------------------------------------------------------------------------------
+static constexpr int LN_NV = 6;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int rows, int C, float eps) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int VPR = C / EPV;
+  float f[LN_NV][EPV];
+  float sum = 0.f;
+  const T* xr = x + (int64_t)row * ldx;
+#pragma unroll
+  for (int j = 0; j < LN_NV; ++j) {
+    const int v = lane + j * 64;
+    if (v < VPR) {
+      unpack16<T>(*(const u32x4*)(xr + v * EPV), f[j]);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) sum += f[j][e];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_NV; ++j) {
+    const int v = lane + j * 64;
+    if (v < VPR) {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { const float d = f[j][e] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+  T* yr = y + (int64_t)row * ldy;
+#pragma unroll
+  for (int j = 0; j < LN_NV; ++j) {
+    const int v = lane + j * 64;
+    if (v < VPR) {
+      float o[EPV];
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) o[e] = (f[j][e] - mean) * rstd * gamma[v * EPV + e] + beta[v * EPV + e];
+      *(u32x4*)(yr + v * EPV) = pack16<T>(o);
+    }
+  }
+}
+
+template <typename T>
+static int ln_launch(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta, int rows, int C,
+                     float eps, hipStream_t s) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  if (C % EPV != 0 || C / EPV > 64 * LN_NV) TANGO_FAIL("layernorm: unsupported C");
+  hipLaunchKernelGGL((layernorm_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const T*)x, ldx, (T*)y, ldy,
+                     gamma, beta, rows, C, eps);
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta,
+                     int rows, int C, float eps, hipStream_t s) {
+  switch (dtype) {
+    case DT_F32: return ln_launch<float>(x, ldx, y, ldy, gamma, beta, rows, C, eps, s);
+    case DT_F16: return ln_launch<f16>(x, ldx, y, ldy, gamma, beta, rows, C, eps, s);
+    case DT_BF16: return ln_launch<bf16>(x, ldx, y, ldy, gamma, beta, rows, C, eps, s);
+  }
+  TANGO_FAIL("layernorm: bad dtype");
+}
+
+// ------------------------------------------------------------------------------------------
+// in-place row softmax(x * scale), one 256-thread block per row, row held in registers
+// ------------------------------------------------------------------------------------------
+static constexpr int SM_NV = 4;
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(T* __restrict__ x, int64_t ld, int cols, float scale) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  T* xr = x + (int64_t)blockIdx.x * ld;
+  const int VPR = cols / EPV;
+  float f[SM_NV][EPV];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < SM_NV; ++j) {
+    const int v = tid + j * 256;
+    if (v < VPR) {
+      unpack16<T>(*(const u32x4*)(xr + v * EPV), f[j]);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { f[j][e] *= scale; mx = fmaxf(mx, f[j][e]); }
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[w] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < SM_NV; ++j) {
+    const int v = tid + j * 256;
+    if (v < VPR) {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { f[j][e] = __expf(f[j][e] - mx); sum += f[j][e]; }
+    }
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + w] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+  for (int j = 0; j < SM_NV; ++j) {
+    const int v = tid + j * 256;
+    if (v < VPR) {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) f[j][e] *= inv;
+      *(u32x4*)(xr + v * EPV) = pack16<T>(f[j]);
+    }
+  }
+}
+
+template <typename T>
+static int sm_launch(void* x, int64_t ld, int rows, int cols, float scale, hipStream_t s) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  if (cols % EPV != 0 || cols / EPV > 256 * SM_NV) TANGO_FAIL("softmax_rows: unsupported cols");
+  hipLaunchKernelGGL((softmax_rows_kernel<T>), dim3((unsigned)rows), dim3(256), 0, s, (T*)x, ld, cols, scale);
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_softmax_rows(int dtype, void* x, int64_t ld, int rows, int cols, float scale, hipStream_t s) {
+  switch (dtype) {
+    case DT_F32: return sm_launch<float>(x, ld, rows, cols, scale, s);
+    case DT_F16: return sm_launch<f16>(x, ld, rows, cols, scale, s);
+    case DT_BF16: return sm_launch<bf16>(x, ld, rows, cols, scale, s);
+  }
+  TANGO_FAIL("softmax_rows: bad dtype");
+}
+
+}  // namespace tango

@@ -1,0 +1,253 @@
+// Per-operator C entry points used by the parity tests (tests/test_ops_gpu.py).  Each takes fp32
+// device tensors in the reference's own layout, converts to the engine dtype/layout, runs the SAME
+// kernels the engine plans use, and converts back.  Not on the product hot path.
+#include <vector>
+
+#include "../../include/tango_engine.h"
+#include "common.h"
+
+namespace tango {
+
+struct Scratch {
+  std::vector<void*> ptrs;
+  ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+  void* get(size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 256) != hipSuccess) return nullptr;
+    ptrs.push_back(p);
+    return p;
+  }
+};
+
+template <typename T>
+__global__ void to_f32_kernel(const T* __restrict__ src, int64_t ld, float* __restrict__ dst, int64_t rows, int C) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * C) return;
+  const int64_t r = i / C;
+  dst[i] = to_f(src[r * ld + (i - r * C)]);
+}
+static int to_f32(int dt, const void* src, int64_t ld, float* dst, int64_t rows, int C, hipStream_t s) {
+  const unsigned nb = (unsigned)((rows * C + 255) / 256);
+  switch (dt) {
+    case DT_F32: hipLaunchKernelGGL((to_f32_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)src, ld, dst, rows, C); break;
+    case DT_F16: hipLaunchKernelGGL((to_f32_kernel<f16>), dim3(nb), dim3(256), 0, s, (const f16*)src, ld, dst, rows, C); break;
+    case DT_BF16: hipLaunchKernelGGL((to_f32_kernel<bf16>), dim3(nb), dim3(256), 0, s, (const bf16*)src, ld, dst, rows, C); break;
+    default: TANGO_FAIL("to_f32: bad dtype");
+  }
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+// [B, C, L] fp32 <-> channels-last T [B*L, C] are the NCHW<->NHWC kernels with HW = L
+}  // namespace tango
+
+using namespace tango;
+
+extern "C" {
+
+int tango_op_conv2d(int dt, const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W, int Cout,
+                    int stride, int upsample, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const size_t esz = dtype_size(dt);
+  Scratch sc;
+  const int Hc = H << upsample, Wc = W << upsample;
+  const int Ho = stride == 2 ? (Hc + 2 - 3) / 2 + 1 : Hc, Wo = stride == 2 ? (Wc + 2 - 3) / 2 + 1 : Wc;
+  const bool im2col = ((Cin * esz) % 64) != 0;
+  const int cpad = im2col ? ((Cin + 7) / 8) * 8 : Cin;
+  void* xt = sc.get((size_t)B * H * W * cpad * esz);
+  void* ot = sc.get((size_t)B * Ho * Wo * Cout * esz);
+  if (!xt || !ot) TANGO_FAIL("op_conv2d: alloc");
+  TANGO_HIP(hipMemsetAsync(xt, 0, (size_t)B * H * W * cpad * esz, s));
+  TANGO_TRY(launch_nchw_to_nhwc(dt, x, xt, cpad, B, Cin, H * W, 1, 1.0f, s));
+  GemmParams p;
+  p.bias = bias; p.N = Cout; p.out = ot; p.ldo = Cout;
+  if (im2col) {
+    if (stride != 1 || upsample) TANGO_FAIL("op_conv2d: small-Cin path supports stride 1 only");
+    const int64_t Kp = ((9 * Cin + 31) / 32) * 32;
+    void* wt = sc.get((size_t)Cout * Kp * esz);
+    void* col = sc.get((size_t)B * H * W * Kp * esz);
+    if (!wt || !col) TANGO_FAIL("op_conv2d: alloc");
+    TANGO_TRY(launch_pack(dt, w, wt, Cout, 9, Cin, (int64_t)Cin * 9, 1, 9, Kp, 0, s));
+    TANGO_TRY(launch_im2col3x3(dt, xt, cpad, col, Kp, B, H, W, Cin, s));
+    p.A = col; p.lda = Kp; p.W = wt; p.Kp = Kp; p.M = B * H * W; p.K = (int)Kp; p.Cin = (int)Kp;
+    p.mode = GATHER_1D; p.rows_pb = p.M; p.Lin = p.M; p.Lout = p.M;
+  } else {
+    const int64_t Kp = 9 * Cin;
+    void* wt = sc.get((size_t)Cout * Kp * esz);
+    if (!wt) TANGO_FAIL("op_conv2d: alloc");
+    TANGO_TRY(launch_pack(dt, w, wt, Cout, 9, Cin, (int64_t)Cin * 9, 1, 9, Kp, 0, s));
+    p.A = xt; p.lda = cpad; p.W = wt; p.Kp = Kp; p.M = B * Ho * Wo; p.K = 9 * Cin; p.Cin = Cin;
+    p.mode = GATHER_2D; p.H = Ho; p.Wd = Wo; p.Hin = H; p.Win = W; p.stride = stride; p.ups = upsample;
+  }
+  TANGO_TRY(launch_gemm(dt, p, s));
+  TANGO_TRY(launch_nhwc_to_nchw_f32(dt, ot, Cout, out, B, Cout, Ho * Wo, s));
+  TANGO_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int tango_op_linear(int dt, const float* x, const float* w, const float* bias, const float* residual, float* out, int M, int N,
+                    int K, int a_act, int e_act, int geglu, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const size_t esz = dtype_size(dt);
+  Scratch sc;
+  const int No = geglu ? N / 2 : N;
+  void* xt = sc.get((size_t)M * K * esz);
+  void* wt = sc.get((size_t)N * K * esz);
+  void* ot = sc.get((size_t)M * No * esz);
+  void* rt = residual ? sc.get((size_t)M * No * esz) : nullptr;
+  float* bt = bias ? (float*)sc.get((size_t)N * 4) : nullptr;
+  if (!xt || !wt || !ot) TANGO_FAIL("op_linear: alloc");
+  TANGO_TRY(launch_cast_rows(dt, x, xt, K, M, K, s));
+  TANGO_TRY(launch_pack(dt, w, wt, N, 1, K, K, 0, 1, K, geglu ? -1 : 0, s));
+  if (residual) TANGO_TRY(launch_cast_rows(dt, residual, rt, No, M, No, s));
+  if (bias) {
+    if (geglu) TANGO_TRY(launch_permute_geglu_bias(bias, bt, N, s));
+    else TANGO_HIP(hipMemcpyAsync(bt, bias, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+  }
+  GemmParams p;
+  p.A = xt; p.lda = K; p.W = wt; p.Kp = K; p.bias = bt; p.M = M; p.N = N; p.K = K; p.Cin = K;
+  p.mode = GATHER_1D; p.rows_pb = M; p.Lin = M; p.Lout = M;
+  p.out = ot; p.ldo = No; p.R = rt; p.ldr = No; p.a_act = a_act; p.e_act = e_act; p.epi = geglu ? EPI_GEGLU : EPI_NONE;
+  TANGO_TRY(launch_gemm(dt, p, s));
+  TANGO_TRY(to_f32(dt, ot, No, out, M, No, s));
+  TANGO_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int tango_op_conv1d(int dt, const float* x, const float* w, const float* bias, const float* residual, float* out, int B, int Cin,
+                    int L, int Cout, int k, int dilation, int a_act, float a_slope, int e_act, float e_slope, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const size_t esz = dtype_size(dt);
+  Scratch sc;
+  void* xt = sc.get((size_t)B * L * Cin * esz);
+  void* wt = sc.get((size_t)Cout * k * Cin * esz);
+  void* ot = sc.get((size_t)B * L * Cout * esz);
+  void* rt = residual ? sc.get((size_t)B * L * Cout * esz) : nullptr;
+  if (!xt || !wt || !ot) TANGO_FAIL("op_conv1d: alloc");
+  TANGO_TRY(launch_nchw_to_nhwc(dt, x, xt, Cin, B, Cin, L, 1, 1.0f, s));
+  if (residual) TANGO_TRY(launch_nchw_to_nhwc(dt, residual, rt, Cout, B, Cout, L, 1, 1.0f, s));
+  TANGO_TRY(launch_pack(dt, w, wt, Cout, k, Cin, (int64_t)Cin * k, 1, k, (int64_t)k * Cin, 0, s));
+  GemmParams p;
+  p.A = xt; p.lda = Cin; p.W = wt; p.Kp = (int64_t)k * Cin; p.bias = bias; p.M = B * L; p.N = Cout; p.K = k * Cin; p.Cin = Cin;
+  p.mode = GATHER_1D; p.rows_pb = L; p.Lin = L; p.taps = k; p.tap_step = dilation; p.in_off = -dilation * (k - 1) / 2;
+  p.Lout = L; p.out = ot; p.ldo = Cout; p.R = rt; p.ldr = Cout;
+  p.a_act = a_act; p.a_slope = a_slope; p.e_act = e_act; p.e_slope = e_slope;
+  TANGO_TRY(launch_gemm(dt, p, s));
+  TANGO_TRY(launch_nhwc_to_nchw_f32(dt, ot, Cout, out, B, Cout, L, s));
+  TANGO_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int tango_op_conv_transpose1d(int dt, const float* x, const float* w, const float* bias, float* out, int B, int Cin, int L,
+                              int Cout, int k, int u, int pd, int a_act, float a_slope, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const size_t esz = dtype_size(dt);
+  Scratch sc;
+  const int Lo = (L - 1) * u - 2 * pd + k;
+  void* xt = sc.get((size_t)B * L * Cin * esz);
+  void* ot = sc.get((size_t)B * Lo * Cout * esz);
+  if (!xt || !ot) TANGO_FAIL("op_convt1d: alloc");
+  TANGO_TRY(launch_nchw_to_nhwc(dt, x, xt, Cin, B, Cin, L, 1, 1.0f, s));
+  for (int r = 0; r < u; ++r) {
+    const int T = (k - r + u - 1) / u;
+    if (T <= 0) continue;
+    void* wt = sc.get((size_t)Cout * T * Cin * esz);
+    if (!wt) TANGO_FAIL("op_convt1d: alloc");
+    TANGO_TRY(launch_pack(dt, w + r, wt, Cout, T, Cin, k, u, (int64_t)Cout * k, (int64_t)T * Cin, 0, s));
+    const int qmin = (pd > r) ? (pd - r + u - 1) / u : 0;
+    const int qmax = (Lo - 1 + pd - r) / u;
+    const int Q = qmax - qmin + 1;
+    if (Q <= 0) continue;
+    GemmParams p;
+    p.A = xt; p.lda = Cin; p.W = wt; p.Kp = (int64_t)T * Cin; p.bias = bias; p.M = B * Q; p.N = Cout; p.K = T * Cin; p.Cin = Cin;
+    p.mode = GATHER_1D; p.rows_pb = Q; p.Lin = L; p.taps = T; p.tap_step = -1; p.in_off = qmin;
+    p.Lout = Lo; p.out_mul = u; p.out_off = u * qmin + r - pd; p.out = ot; p.ldo = Cout;
+    p.a_act = a_act; p.a_slope = a_slope;
+    TANGO_TRY(launch_gemm(dt, p, s));
+  }
+  TANGO_TRY(launch_nhwc_to_nchw_f32(dt, ot, Cout, out, B, Cout, Lo, s));
+  TANGO_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int tango_op_groupnorm(int dt, const float* x, const float* gamma, const float* beta, float* out, int B, int C, int HW, int groups,
+                       float eps, int act, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const size_t esz = dtype_size(dt);
+  Scratch sc;
+  void* xt = sc.get((size_t)B * HW * C * esz);
+  void* yt = sc.get((size_t)B * HW * C * esz);
+  const size_t nf = groupnorm_ws_floats(B, HW, C, groups);
+  float* ws = (float*)sc.get(nf * 4);
+  if (!xt || !yt || !ws) TANGO_FAIL("op_groupnorm: alloc");
+  TANGO_TRY(launch_nchw_to_nhwc(dt, x, xt, C, B, C, HW, 1, 1.0f, s));
+  GroupNormParams p;
+  p.x = xt; p.ldx = C; p.y = yt; p.ldy = C; p.gamma = gamma; p.beta = beta; p.B = B; p.rows = HW; p.C = C; p.groups = groups;
+  p.eps = eps; p.act = act; p.partial = ws; p.scale_shift = ws + (nf - (size_t)B * C * 2);
+  TANGO_TRY(launch_groupnorm(dt, p, s));
+  TANGO_TRY(launch_nhwc_to_nchw_f32(dt, yt, C, out, B, C, HW, s));
+  TANGO_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int tango_op_layernorm(int dt, const float* x, const float* gamma, const float* beta, float* out, int rows, int C, float eps,
+                       void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const size_t esz = dtype_size(dt);
+  Scratch sc;
+  void* xt = sc.get((size_t)rows * C * esz);
+  void* yt = sc.get((size_t)rows * C * esz);
+  if (!xt || !yt) TANGO_FAIL("op_layernorm: alloc");
+  TANGO_TRY(launch_cast_rows(dt, x, xt, C, rows, C, s));
+  TANGO_TRY(launch_layernorm(dt, xt, C, yt, C, gamma, beta, rows, C, eps, s));
+  TANGO_TRY(to_f32(dt, yt, C, out, rows, C, s));
+  TANGO_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int tango_op_attention(int dt, const float* q, const float* k, const float* v, const float* bias, float* out, int B, int heads,
+                       int Sq, int Skv, float scale, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const size_t esz = dtype_size(dt);
+  Scratch sc;
+  const int C = heads * 64;
+  void* qt = sc.get((size_t)B * Sq * C * esz);
+  void* kt = sc.get((size_t)B * Skv * C * esz);
+  void* vt = sc.get((size_t)B * Skv * C * esz);
+  void* ot = sc.get((size_t)B * Sq * C * esz);
+  if (!qt || !kt || !vt || !ot) TANGO_FAIL("op_attention: alloc");
+  TANGO_TRY(launch_cast_rows(dt, q, qt, C, B * Sq, C, s));
+  TANGO_TRY(launch_cast_rows(dt, k, kt, C, B * Skv, C, s));
+  TANGO_TRY(launch_cast_rows(dt, v, vt, C, B * Skv, C, s));
+  AttnParams p;
+  p.q = qt; p.ldq = C; p.k = kt; p.ldk = C; p.v = vt; p.ldv = C; p.o = ot; p.ldo = C; p.bias = bias;
+  p.B = B; p.heads = heads; p.Sq = Sq; p.Skv = Skv; p.scale = scale;
+  TANGO_TRY(launch_attention(dt, p, s));
+  TANGO_TRY(to_f32(dt, ot, C, out, (int64_t)B * Sq, C, s));
+  TANGO_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int tango_op_sched_step(float* latents, const float* model_out_nchw, const float* noise, const float* coef8, int B, int C, int HW,
+                        int cfg, float guidance, int pred_type, int rule, int clip, float clip_range, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Scratch sc;
+  const int B2 = cfg ? 2 * B : B;
+  float* eps = (float*)sc.get((size_t)B2 * HW * C * 4);
+  float* xin = (float*)sc.get((size_t)B2 * HW * 8 * 4);
+  float* dcoef = (float*)sc.get(8 * 4);
+  int* dstep = (int*)sc.get(256);
+  if (!eps || !xin || !dcoef || !dstep) TANGO_FAIL("op_sched_step: alloc");
+  TANGO_TRY(launch_nchw_to_nhwc(DT_F32, model_out_nchw, eps, C, B2, C, HW, 1, 1.0f, s));
+  TANGO_HIP(hipMemcpyAsync(dcoef, coef8, 32, hipMemcpyHostToDevice, s));
+  TANGO_HIP(hipMemsetAsync(dstep, 0, 4, s));
+  SchedParams p;
+  p.lat = latents; p.eps = eps; p.xin = xin; p.xin_ld = 8; p.noise = noise; p.coef = dcoef; p.step_ptr = dstep;
+  p.B = B; p.C = C; p.HW = HW; p.cfg = cfg; p.guidance = guidance; p.pred_type = pred_type; p.rule = rule; p.clip = clip;
+  p.clip_range = clip_range; p.seed = 0; p.sample_offset = 0;
+  TANGO_TRY(launch_sched_step(DT_F32, p, s));
+  TANGO_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+}  // extern "C"

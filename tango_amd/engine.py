@@ -1,0 +1,246 @@
+"""Thin Python handle over the C-ABI engine.  PyTorch is plumbing only: device memory, streams."""
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import weights as W
+
+#: configs/diffusion_model_config.json of the reference (FLAN-T5-large Tango / Tango-full / Tango2)
+UNET_CONFIG_LARGE = dict(
+    in_channels=8, out_channels=8, block_out_channels=[320, 640, 1280, 1280],
+    attention_head_dim=[5, 10, 20, 20], layers_per_block=2, cross_attention_dim=1024,
+    down_block_types=["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"],
+    up_block_types=["UpBlock2D"] + ["CrossAttnUpBlock2D"] * 3,
+    norm_num_groups=32, norm_eps=1e-5, flip_sin_to_cos=True, freq_shift=0,
+)
+UNET_CONFIG_XL = dict(UNET_CONFIG_LARGE, cross_attention_dim=2048)
+#: mustango/configs/vae_config.json ddconfig + scale_factor
+VAE_CONFIG = dict(ch=128, ch_mult=[1, 2, 4], num_res_blocks=2, z_channels=8, out_ch=1, embed_dim=8,
+                  scale_factor=0.9227914214134216)
+#: audioldm/hifigan/utilities.py:9-39
+HIFIGAN_CONFIG = dict(upsample_rates=[5, 4, 2, 2, 2], upsample_kernel_sizes=[16, 16, 8, 4, 4],
+                      upsample_initial_channel=1024, resblock_kernel_sizes=[3, 7, 11],
+                      resblock_dilation_sizes=[[1, 3, 5]] * 3, num_mels=64)
+
+
+def normalize_unet_config(cfg: dict) -> dict:
+    out = dict(UNET_CONFIG_LARGE)
+    for k in out:
+        if k in cfg:
+            out[k] = cfg[k]
+    if isinstance(out["attention_head_dim"], int):
+        out["attention_head_dim"] = [out["attention_head_dim"]] * len(out["block_out_channels"])
+    return out
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """One engine handle = one (device, model) pair; not re-entrant (include/tango_engine.h)."""
+
+    def __init__(self, unet: Optional[dict] = None, vae: Optional[dict] = None, hifigan: Optional[dict] = None,
+                 dtype: str = "fp16", device="cuda:0"):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("tango_amd.Engine needs a HIP device (no CPU fallback)")
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.unet_cfg = normalize_unet_config(unet) if unet is not None else None
+        self.vae_cfg = dict(vae) if vae is not None else None
+        self.hifigan_cfg = dict(hifigan) if hifigan is not None else None
+        c = _lib.TangoConfig()
+        c.dtype = _lib.DTYPES[dtype]
+        c.latent_h, c.latent_w = 256, 16
+        if self.unet_cfg is not None:
+            u = self.unet_cfg
+            ch = u["block_out_channels"]
+            c.unet_levels = len(ch)
+            for i, v in enumerate(ch):
+                c.unet_channels[i] = v
+                c.unet_heads[i] = u["attention_head_dim"][i]
+                c.unet_cross_attn[i] = 1 if u["down_block_types"][i] == "CrossAttnDownBlock2D" else 0
+            c.unet_layers_per_block = u["layers_per_block"]
+            c.unet_in_channels = u["in_channels"]
+            c.unet_out_channels = u["out_channels"]
+            c.unet_cross_dim = u["cross_attention_dim"]
+            c.unet_groups = u["norm_num_groups"]
+            c.unet_eps = u["norm_eps"]
+            c.unet_flip_sin_to_cos = 1 if u["flip_sin_to_cos"] else 0
+            c.unet_freq_shift = float(u["freq_shift"])
+        if self.vae_cfg is not None:
+            v = self.vae_cfg
+            c.vae_levels = len(v["ch_mult"])
+            c.vae_ch = v["ch"]
+            for i, m in enumerate(v["ch_mult"]):
+                c.vae_ch_mult[i] = m
+            c.vae_num_res_blocks = v["num_res_blocks"]
+            c.vae_z_channels = v["z_channels"]
+            c.vae_embed_dim = v.get("embed_dim", 8)
+            c.vae_out_ch = v["out_ch"]
+            c.vae_scale_factor = v["scale_factor"]
+        if self.hifigan_cfg is not None:
+            h = self.hifigan_cfg
+            c.voc_n_ups = len(h["upsample_rates"])
+            for i, (r, k) in enumerate(zip(h["upsample_rates"], h["upsample_kernel_sizes"])):
+                c.voc_rates[i] = r
+                c.voc_kernels[i] = k
+            c.voc_initial_channel = h["upsample_initial_channel"]
+            c.voc_num_mels = h["num_mels"]
+            c.voc_n_resblocks = len(h["resblock_kernel_sizes"])
+            for j, k in enumerate(h["resblock_kernel_sizes"]):
+                c.voc_res_kernels[j] = k
+                for m, d in enumerate(h["resblock_dilation_sizes"][j]):
+                    c.voc_res_dilations[j][m] = d
+        self._cfg = c
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.tango_engine_create(C.byref(c), C.byref(self._h)), "tango_engine_create")
+        self._finalized = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.tango_engine_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- weights -------------------------------------------------------------------------
+    def weight_names(self):
+        n = self.lib.tango_engine_num_weights(self._h)
+        return [self.lib.tango_engine_weight_name(self._h, i).decode() for i in range(n)]
+
+    def expected_shapes(self) -> Dict[str, tuple]:
+        out = {}
+        if self.unet_cfg is not None:
+            out.update(W.unet_param_shapes(self.unet_cfg, "unet."))
+        if self.vae_cfg is not None:
+            out.update(W.vae_decoder_param_shapes(self.vae_cfg))
+        if self.hifigan_cfg is not None:
+            out.update(W.hifigan_param_shapes(self.hifigan_cfg))
+        return out
+
+    def set_weight(self, name: str, tensor: torch.Tensor):
+        t = tensor.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.tango_engine_set_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()),
+                       "set_weight(%s)" % name)
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "", strict: bool = True):
+        """Ingest reference-named tensors (pytorch_model_main.bin / pytorch_model_vae.bin keys).
+        Keys the engine does not need (text_encoder.*, encoder.*, quant_conv.*) are ignored."""
+        need = set(self.weight_names())
+        for k in list(need):
+            src = prefix + k
+            if src in sd:
+                self.set_weight(k, sd[src])
+                need.discard(k)
+        if strict and need:
+            raise RuntimeError("Missing key(s) in state_dict: %s ..." % sorted(need)[:4])
+        return sorted(need)
+
+    def load_synthetic(self, seed: int = 1234):
+        """Seeded synthetic weights (tango_amd.weights.synth_tensor), streamed tensor by tensor."""
+        shapes = self.expected_shapes()
+        for k in self.weight_names():
+            self.set_weight(k, W.synth_tensor(k, shapes[k], seed))
+        self.finalize()
+
+    def finalize(self):
+        _lib.check(self.lib.tango_engine_finalize_weights(self._h), "finalize_weights")
+        self._finalized = True
+
+    # ---- compute -------------------------------------------------------------------------
+    def _f32(self, t):
+        return t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+
+    def unet_forward(self, sample, timestep, encoder_hidden_states, encoder_attention_mask=None):
+        x = self._f32(sample)
+        enc = self._f32(encoder_hidden_states)
+        B2, L = enc.shape[0], enc.shape[1]
+        mask = None
+        if encoder_attention_mask is not None:
+            mask = encoder_attention_mask.to(self.device).to(torch.uint8).contiguous()
+        out = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.tango_engine_unet_forward(
+                self._h, C.c_void_p(x.data_ptr()), int(timestep), C.c_void_p(enc.data_ptr()),
+                C.c_void_p(mask.data_ptr()) if mask is not None else None, C.c_void_p(out.data_ptr()), B2, L,
+                _stream_ptr()), "unet_forward")
+        return out
+
+    def denoise(self, latents, prompt_embeds, prompt_mask, timesteps, coef, guidance_scale, prediction_type="v_prediction",
+                rule="ddpm", clip_sample=False, clip_sample_range=1.0, noise=None, seed=0, sample_offset=0, use_graph=True):
+        """In-place denoise of `latents` [B,8,256,16] (fp32 cuda).  `timesteps` int64 [N] and `coef`
+        float32 [N,8] are host tables from tango_amd.scheduler."""
+        assert latents.is_cuda and latents.dtype == torch.float32 and latents.is_contiguous()
+        enc = self._f32(prompt_embeds)
+        mask = prompt_mask.to(self.device).to(torch.uint8).contiguous() if prompt_mask is not None else None
+        ts = np.ascontiguousarray(np.asarray(timesteps, dtype=np.int64))
+        cf = np.ascontiguousarray(np.asarray(coef, dtype=np.float32))
+        assert cf.shape == (len(ts), 8)
+        if noise is not None:
+            noise = self._f32(noise)
+            assert noise.shape[0] == len(ts)
+        a = _lib.DenoiseArgs()
+        a.latents = latents.data_ptr()
+        a.prompt_embeds = enc.data_ptr()
+        a.prompt_mask = mask.data_ptr() if mask is not None else None
+        a.batch = latents.shape[0]
+        a.text_len = enc.shape[1]
+        a.num_steps = len(ts)
+        a.timesteps = ts.ctypes.data
+        a.coef = cf.ctypes.data
+        a.guidance_scale = float(guidance_scale)
+        a.prediction_type = _lib.PRED[prediction_type]
+        a.rule = _lib.RULE[rule]
+        a.clip_sample = 1 if clip_sample else 0
+        a.clip_sample_range = float(clip_sample_range)
+        a.noise = noise.data_ptr() if noise is not None else None
+        a.seed = int(seed)
+        a.sample_offset = int(sample_offset)
+        a.use_graph = 1 if use_graph else 0
+        expect = 2 * a.batch if guidance_scale > 1.0 else a.batch
+        if enc.shape[0] != expect:
+            raise ValueError("prompt_embeds batch %d != %d" % (enc.shape[0], expect))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.tango_engine_denoise(self._h, C.byref(a), _stream_ptr()), "denoise")
+        return latents
+
+    def last_denoise_ms(self):
+        tot, per = C.c_float(), C.c_float()
+        _lib.check(self.lib.tango_engine_last_denoise_ms(self._h, C.byref(tot), C.byref(per)), "last_denoise_ms")
+        return tot.value, per.value
+
+    def vae_decode(self, latents):
+        z = self._f32(latents)
+        B = z.shape[0]
+        nl = len(self.vae_cfg["ch_mult"])
+        mel = torch.empty((B, self.vae_cfg["out_ch"], z.shape[2] << (nl - 1), z.shape[3] << (nl - 1)),
+                          device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.tango_engine_vae_decode(self._h, C.c_void_p(z.data_ptr()), C.c_void_p(mel.data_ptr()), B,
+                                                        _stream_ptr()), "vae_decode")
+        return mel
+
+    def vocoder_samples(self, frames: int) -> int:
+        return self.lib.tango_engine_vocoder_samples(self._h, frames)
+
+    def vocode(self, mel):
+        """mel [B,1,T,num_mels] fp32 -> int16 cuda tensor [B, samples]"""
+        m = self._f32(mel)
+        B, T = m.shape[0], m.shape[2]
+        n = self.vocoder_samples(T)
+        wav = torch.empty((B, n), device=self.device, dtype=torch.int16)
+        ns = C.c_int()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.tango_engine_vocode(self._h, C.c_void_p(m.data_ptr()), C.c_void_p(wav.data_ptr()), B, T,
+                                                    C.byref(ns), _stream_ptr()), "vocode")
+        assert ns.value == n
+        return wav

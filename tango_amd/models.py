@@ -1,0 +1,169 @@
+"""`AudioDiffusion` -- drop-in for the inference-side surface of the reference class
+(models.py:55-305 of declare-lab/tango): `inference`, `prepare_latents`, `encode_text`,
+`encode_text_classifier_free`, `.unet.config.in_channels`.  Training (`forward`, `compute_snr`) is
+out of scope.
+
+The denoise loop (models.py:233-249) runs inside the HIP engine; the frozen FLAN-T5 encoder stays a
+PyTorch-ROCm module (its output is the engine's input).
+"""
+import json
+import os
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+
+from .engine import Engine, normalize_unet_config
+from .scheduler import DDIMScheduler, DDPMScheduler  # noqa: F401  (re-exported like `from models import DDPMScheduler`)
+
+_TEXT_BUCKETS = (16, 32, 64, 128, 256, 512)
+
+
+class _UNetHandle:
+    """What callers read off `model.unet` (models.py:227)."""
+
+    def __init__(self, cfg, engine):
+        self.config = SimpleNamespace(**cfg)
+        self.in_channels = cfg["in_channels"]
+        self._engine = engine
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None, encoder_attention_mask=None, **_):
+        out = self._engine.unet_forward(sample, int(timestep), encoder_hidden_states, encoder_attention_mask)
+        return SimpleNamespace(sample=out)
+
+
+class AudioDiffusion:
+    def __init__(self, text_encoder_name=None, scheduler_name=None, unet_model_name=None, unet_model_config_path=None,
+                 snr_gamma=None, freeze_text_encoder=True, uncondition=False, *, unet_config: Optional[dict] = None,
+                 dtype: str = "fp16", device="cuda:0", text_encoder=None, tokenizer=None, bucket_text_len: bool = True):
+        assert unet_model_name is None, "released Tango checkpoints take the set_from == 'random' branch (models.py:83-86)"
+        if unet_config is None:
+            if unet_model_config_path is None:
+                raise ValueError("Either UNet pretrain model name or a config file path is required")
+            unet_config = json.load(open(unet_model_config_path))
+        self.unet_config = normalize_unet_config({k: v for k, v in unet_config.items() if not k.startswith("_")})
+        self.text_encoder_name = text_encoder_name
+        self.scheduler_name = scheduler_name
+        self.set_from = "random"
+        self.device = torch.device(device)
+        self.engine = Engine(unet=self.unet_config, dtype=dtype, device=device)
+        self.unet = _UNetHandle(self.unet_config, self.engine)
+        self.text_encoder = text_encoder
+        self.tokenizer = tokenizer
+        self.bucket_text_len = bucket_text_len
+        self.use_graph = True
+        self.seed = 0
+        self._calls = 0
+
+    # ---- state dict --------------------------------------------------------------------------
+    def load_state_dict(self, sd, strict=True):
+        """pytorch_model_main.bin: `unet.*` goes to the engine, `text_encoder.*` to the torch T5."""
+        missing = self.engine.load_state_dict(sd, strict=strict)
+        self.engine.finalize()
+        if self.text_encoder is not None:
+            te = {k[len("text_encoder."):]: v for k, v in sd.items() if k.startswith("text_encoder.")}
+            if te:
+                self.text_encoder.load_state_dict(te, strict=False)
+        return missing
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    # ---- text --------------------------------------------------------------------------------
+    def _ensure_text(self):
+        if self.text_encoder is None or self.tokenizer is None:
+            from transformers import AutoTokenizer, T5EncoderModel   # models.py:98-100
+            self.tokenizer = AutoTokenizer.from_pretrained(self.text_encoder_name)
+            self.text_encoder = T5EncoderModel.from_pretrained(self.text_encoder_name).to(self.device).eval()
+
+    def encode_text(self, prompt: List[str]):
+        """models.py:129-147"""
+        self._ensure_text()
+        batch = self.tokenizer(prompt, max_length=self.tokenizer.model_max_length, padding=True, truncation=True,
+                               return_tensors="pt")
+        ids, am = batch.input_ids.to(self.device), batch.attention_mask.to(self.device)
+        with torch.no_grad():
+            hs = self.text_encoder(input_ids=ids, attention_mask=am)[0]
+        return hs, (am == 1).to(self.device)
+
+    def encode_text_classifier_free(self, prompt: List[str], num_samples_per_prompt: int):
+        """models.py:266-305: returns [uncond; cond] embeddings and the boolean mask."""
+        self._ensure_text()
+        dev = self.device
+        batch = self.tokenizer(prompt, max_length=self.tokenizer.model_max_length, padding=True, truncation=True,
+                               return_tensors="pt")
+        ids, am = batch.input_ids.to(dev), batch.attention_mask.to(dev)
+        with torch.no_grad():
+            pe = self.text_encoder(input_ids=ids, attention_mask=am)[0]
+        pe = pe.repeat_interleave(num_samples_per_prompt, 0)
+        am = am.repeat_interleave(num_samples_per_prompt, 0)
+        ub = self.tokenizer([""] * len(prompt), max_length=pe.shape[1], padding="max_length", truncation=True,
+                            return_tensors="pt")
+        uids, uam = ub.input_ids.to(dev), ub.attention_mask.to(dev)
+        with torch.no_grad():
+            ne = self.text_encoder(input_ids=uids, attention_mask=uam)[0]
+        ne = ne.repeat_interleave(num_samples_per_prompt, 0)
+        uam = uam.repeat_interleave(num_samples_per_prompt, 0)
+        return torch.cat([ne, pe]), (torch.cat([uam, am]) == 1).to(dev)
+
+    # ---- latents -----------------------------------------------------------------------------
+    def prepare_latents(self, batch_size, inference_scheduler, num_channels_latents, dtype, device):
+        """models.py:259-264 (global torch generator on `device`, like the reference)."""
+        shape = (batch_size, num_channels_latents, 256, 16)
+        latents = torch.randn(shape, device=device, dtype=dtype)
+        return latents * inference_scheduler.init_noise_sigma
+
+    # ---- the hot path ------------------------------------------------------------------------
+    def _pad_text(self, embeds, mask):
+        """Static plan shapes: pad L up to a bucket with masked tokens.  Numerically exact: a masked
+        key's weight is exp(-10000) == 0 in fp32 (SURVEY.md section 4 differential check)."""
+        L = embeds.shape[1]
+        if not self.bucket_text_len:
+            return embeds, mask
+        tgt = next((b for b in _TEXT_BUCKETS if b >= L), L)
+        if tgt == L:
+            return embeds, mask
+        pe = torch.zeros((embeds.shape[0], tgt, embeds.shape[2]), device=embeds.device, dtype=embeds.dtype)
+        pe[:, :L] = embeds
+        pm = torch.zeros((mask.shape[0], tgt), device=mask.device, dtype=torch.bool)
+        pm[:, :L] = mask
+        return pe, pm
+
+    @torch.no_grad()
+    def inference_from_embeddings(self, prompt_embeds, boolean_prompt_mask, inference_scheduler, num_steps=20,
+                                  guidance_scale=3, latents=None, noise=None, seed=None, sample_offset=0):
+        """Loop of models.py:224-249 given the encoder outputs ([uncond; cond] when guidance > 1)."""
+        cfg_on = guidance_scale > 1.0
+        B = prompt_embeds.shape[0] // 2 if cfg_on else prompt_embeds.shape[0]
+        inference_scheduler.set_timesteps(num_steps, device=self.device)
+        timesteps = inference_scheduler.timesteps
+        if latents is None:
+            latents = self.prepare_latents(B, inference_scheduler, self.unet.config.in_channels, torch.float32, self.device)
+        latents = latents.to(self.device, torch.float32).contiguous().clone()
+        if boolean_prompt_mask is None:
+            boolean_prompt_mask = torch.ones(prompt_embeds.shape[:2], dtype=torch.bool, device=prompt_embeds.device)
+        pe, pm = self._pad_text(prompt_embeds.to(self.device), boolean_prompt_mask.to(self.device))
+        c = inference_scheduler.config
+        if seed is None:
+            seed = (self.seed << 20) + self._calls
+        self._calls += 1
+        self.engine.denoise(latents, pe, pm, timesteps.cpu().numpy(), inference_scheduler.coef_table(), guidance_scale,
+                            prediction_type=c.prediction_type, rule=inference_scheduler.rule, clip_sample=c.clip_sample,
+                            clip_sample_range=getattr(c, "clip_sample_range", 1.0), noise=noise, seed=seed,
+                            sample_offset=sample_offset, use_graph=self.use_graph)
+        return latents
+
+    @torch.no_grad()
+    def inference(self, prompt, inference_scheduler, num_steps=20, guidance_scale=3, num_samples_per_prompt=1,
+                  disable_progress=True):
+        """models.py:210-257 (same signature, same return: latents [B*S, 8, 256, 16])."""
+        if guidance_scale > 1.0:
+            pe, pm = self.encode_text_classifier_free(prompt, num_samples_per_prompt)
+        else:
+            pe, pm = self.encode_text(prompt)
+            pe = pe.repeat_interleave(num_samples_per_prompt, 0)
+            pm = pm.repeat_interleave(num_samples_per_prompt, 0)
+        return self.inference_from_embeddings(pe.float(), pm, inference_scheduler, num_steps, guidance_scale)

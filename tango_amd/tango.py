@@ -1,0 +1,91 @@
+"""`Tango` -- drop-in for tango.py:9-64 of the reference: same constructor, `generate`,
+`generate_for_batch`; the three hot calls (inference -> decode_first_stage -> decode_to_waveform) run
+on the HIP engine.  `name` may be a local directory holding the HF snapshot files
+(vae_config.json, main_config.json, pytorch_model_{vae,main}.bin); hub download is attempted otherwise.
+"""
+import json
+import os
+
+import torch
+
+from .autoencoder import AutoencoderKL
+from .models import AudioDiffusion
+from .scheduler import SD21_SCHEDULER_CONFIG, DDPMScheduler
+
+_CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
+
+
+class Tango:
+    def __init__(self, name="declare-lab/tango", device="cuda:0", dtype="fp16", scheduler_config=None):
+        if os.path.isdir(name):
+            path = name
+        else:
+            from huggingface_hub import snapshot_download   # tango.py:12
+            path = snapshot_download(repo_id=name)
+        vae_config = json.load(open("{}/vae_config.json".format(path)))
+        main_config = json.load(open("{}/main_config.json".format(path)))
+        self.vae = AutoencoderKL(**vae_config, dtype=dtype, device=device)
+        cfg_path = main_config.get("unet_model_config_path")
+        if cfg_path is None or not os.path.exists(cfg_path):
+            # the reference resolves configs/diffusion_model_config.json relative to the cwd (models.py:83-85)
+            base = os.path.basename(cfg_path) if cfg_path else "diffusion_model_config.json"
+            cfg_path = os.path.join(_CONFIG_DIR, base)
+        main_config = dict(main_config, unet_model_config_path=cfg_path)
+        self.model = AudioDiffusion(**main_config, dtype=dtype, device=device)
+        vae_weights = torch.load("{}/pytorch_model_vae.bin".format(path), map_location="cpu")
+        main_weights = torch.load("{}/pytorch_model_main.bin".format(path), map_location="cpu")
+        self.vae.load_state_dict(vae_weights)
+        self.model.load_state_dict(main_weights)
+        print("Successfully loaded checkpoint from:", name)
+        self.vae.eval()
+        self.model.eval()
+        # tango.py:36 pulls stabilityai/stable-diffusion-2-1's scheduler JSON from the hub; config is data here
+        self.scheduler = DDPMScheduler.from_config(_ddpm_keys(scheduler_config or SD21_SCHEDULER_CONFIG))
+
+    @classmethod
+    def from_components(cls, model: AudioDiffusion, vae: AutoencoderKL, scheduler=None):
+        """Assemble from already-built components (synthetic-weight benchmarks, tests)."""
+        self = cls.__new__(cls)
+        self.model, self.vae = model, vae
+        self.scheduler = scheduler or DDPMScheduler.from_config(_ddpm_keys(SD21_SCHEDULER_CONFIG))
+        return self
+
+    def chunks(self, lst, n):
+        """ Yield successive n-sized chunks from a list. """
+        for i in range(0, len(lst), n):
+            yield lst[i:i + n]
+
+    def generate(self, prompt, steps=100, guidance=3, samples=1, disable_progress=True):
+        """ Generate audio for a single prompt string. (tango.py:43-49) """
+        with torch.no_grad():
+            latents = self.model.inference([prompt], self.scheduler, steps, guidance, samples, disable_progress=disable_progress)
+            mel = self.vae.decode_first_stage(latents)
+            wave = self.vae.decode_to_waveform(mel)
+        return wave[0]
+
+    def generate_for_batch(self, prompts, steps=100, guidance=3, samples=1, batch_size=8, disable_progress=True):
+        """ Generate audio for a list of prompt strings. (tango.py:51-64) """
+        outputs = []
+        for k in range(0, len(prompts), batch_size):
+            batch = prompts[k: k + batch_size]
+            with torch.no_grad():
+                latents = self.model.inference(batch, self.scheduler, steps, guidance, samples, disable_progress=disable_progress)
+                mel = self.vae.decode_first_stage(latents)
+                wave = self.vae.decode_to_waveform(mel)
+                outputs += [item for item in wave]
+        if samples == 1:
+            return outputs
+        return list(self.chunks(outputs, samples))
+
+    def generate_from_embeddings(self, prompt_embeds, boolean_prompt_mask, steps=100, guidance=3, **kw):
+        """Same three calls given the text-encoder outputs (benchmarks / data-parallel workers)."""
+        with torch.no_grad():
+            latents = self.model.inference_from_embeddings(prompt_embeds, boolean_prompt_mask, self.scheduler, steps, guidance, **kw)
+            mel = self.vae.decode_first_stage(latents)
+            return self.vae.decode_to_waveform(mel)
+
+
+def _ddpm_keys(cfg):
+    keep = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "prediction_type", "clip_sample",
+            "variance_type", "clip_sample_range")
+    return {k: v for k, v in cfg.items() if k in keep}

@@ -1,0 +1,185 @@
+"""Module-level parity through the C ABI: HIP engine vs the CPU oracle on the same seeded inputs.
+
+Stated tolerances: fp32 engine, one UNet forward: max-abs <= 1e-3 * max|y|; short loop
+with injected identical noise: latents max-abs <= 1e-2; int16 wave: <= 1 LSB on >= 99.9 % of samples
+given the same mel (fp32).  fp16 engine (fp16 storage / MFMA operands, fp32 accumulate + statistics):
+one UNet forward <= 3e-2 * max|y|."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tango_oracle as O  # noqa: E402  (checker only)
+from tango_amd import weights as W  # noqa: E402
+from tango_amd.engine import Engine  # noqa: E402
+from tango_amd.scheduler import DDIMScheduler, DDPMScheduler, SD21_SCHEDULER_CONFIG  # noqa: E402
+
+UTOL = {"fp32": 1e-3, "fp16": 3e-2, "bf16": 2e-1}
+_cache = {}
+
+
+def unet_engine(name, dtype):
+    key = ("unet", name, dtype)
+    if key not in _cache:
+        cfg = {"tiny": O.UNET_CONFIG_TINY, "large": O.UNET_CONFIG_LARGE}[name]
+        e = Engine(unet=cfg, dtype=dtype)
+        e.load_synthetic(1234)
+        _cache[key] = e
+    return _cache[key]
+
+
+def unet_sd(name):
+    key = ("unet_sd", name)
+    if key not in _cache:
+        cfg = {"tiny": O.UNET_CONFIG_TINY, "large": O.UNET_CONFIG_LARGE}[name]
+        _cache[key] = W.synth_state_dict(W.unet_param_shapes(cfg, "unet."), 1234)
+    return _cache[key]
+
+
+def text_inputs(B2, L, d, seed, ragged=True):
+    g = torch.Generator().manual_seed(seed)
+    enc = torch.randn(B2, L, d, generator=g)
+    mask = torch.ones(B2, L, dtype=torch.bool)
+    if ragged:
+        mask[0, 1:] = False            # the uncond row of T5("") attends to token 0 only (models.py:282-289)
+        if B2 > 2:
+            mask[2, L // 2:] = False
+    return enc, mask
+
+
+def relerr(a, b):
+    return ((a - b).abs().max() / (b.abs().max() + 1e-9)).item()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16", "bf16"])
+def test_unet_forward_tiny(dtype):
+    cfg = O.UNET_CONFIG_TINY
+    e = unet_engine("tiny", dtype)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 8, 256, 16, generator=g)
+    enc, mask = text_inputs(4, 13, cfg["cross_attention_dim"], 12)
+    ref = O.unet_forward(unet_sd("tiny"), cfg, x, 801, enc, mask, prefix="unet.")
+    out = e.unet_forward(x.cuda(), 801, enc.cuda(), mask.cuda()).cpu()
+    err = relerr(out, ref)
+    print("unet tiny %s rel err %.3e" % (dtype, err))
+    assert err <= UTOL[dtype]
+    # no-mask path and another timestep
+    ref2 = O.unet_forward(unet_sd("tiny"), cfg, x[:2], 5, enc[:2], None, prefix="unet.")
+    out2 = e.unet_forward(x[:2].cuda(), 5, enc[:2].cuda(), None).cpu()
+    assert relerr(out2, ref2) <= UTOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_unet_forward_large(dtype):
+    """Full Tango UNet (866 M params, configs/diffusion_model_config.json), one CFG pair, L = 64."""
+    cfg = O.UNET_CONFIG_LARGE
+    e = unet_engine("large", dtype)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 8, 256, 16, generator=g)
+    enc, mask = text_inputs(2, 64, 1024, 22)
+    ref = O.unet_forward(unet_sd("large"), cfg, x, 995, enc, mask, prefix="unet.")
+    out = e.unet_forward(x.cuda(), 995, enc.cuda(), mask.cuda()).cpu()
+    err = relerr(out, ref)
+    print("unet large %s rel err %.3e" % (dtype, err))
+    assert err <= UTOL[dtype]
+    _cache.pop(("unet", "large", dtype), None)   # free 3.5/1.7 GB of packed weights
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("sched_name", ["ddpm", "ddim"])
+def test_denoise_loop_tiny(dtype, sched_name):
+    """models.py:224-249 with injected noise, 4 steps, guidance 3: engine loop (hipGraph and eager) vs oracle."""
+    cfg = O.UNET_CONFIG_TINY
+    e = unet_engine("tiny", dtype)
+    B, L, N = 2, 9, 4
+    enc, mask = text_inputs(2 * B, L, cfg["cross_attention_dim"], 31)
+    g = torch.Generator().manual_seed(32)
+    lat0 = torch.randn(B, 8, 256, 16, generator=g)
+    noises = torch.randn(N, B, 8, 256, 16, generator=g)
+    if sched_name == "ddpm":
+        osch = O.DDPMOracle(**O.SD21_SCHEDULER)
+        keys = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "prediction_type", "clip_sample", "variance_type")
+        sch = DDPMScheduler.from_config({k: SD21_SCHEDULER_CONFIG[k] for k in keys})
+    else:
+        osch = O.DDIMOracle(**dict(O.SD21_SCHEDULER, set_alpha_to_one=False, steps_offset=1))
+        keys = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "prediction_type", "clip_sample", "set_alpha_to_one", "steps_offset")
+        sch = DDIMScheduler.from_config({k: SD21_SCHEDULER_CONFIG[k] for k in keys})
+    if sched_name == "ddpm":
+        ref = O.denoise_loop(unet_sd("tiny"), cfg, osch, enc, mask, lat0.clone(), N, 3.0, noises=list(noises), prefix="unet.")
+    else:
+        osch.set_timesteps(N)
+        lat = lat0.clone()
+        for t in osch.timesteps:
+            out = O.unet_forward(unet_sd("tiny"), cfg, torch.cat([lat] * 2), t, enc, mask, prefix="unet.")
+            u, c = out.chunk(2)
+            lat = osch.step(u + 3.0 * (c - u), t, lat)
+        ref = lat
+    sch.set_timesteps(N)
+    assert sch.timesteps.tolist() == osch.timesteps.tolist()
+    outs = []
+    for use_graph in (True, False):
+        lat = lat0.clone().cuda()
+        e.denoise(lat, enc.cuda(), mask.cuda(), sch.timesteps.numpy(), sch.coef_table(), 3.0,
+                  prediction_type="v_prediction", rule=sch.rule, noise=noises.cuda() if sched_name == "ddpm" else None,
+                  use_graph=use_graph)
+        torch.cuda.synchronize()
+        outs.append(lat.cpu())
+    assert torch.equal(outs[0], outs[1]), "hipGraph replay and eager launches must agree bit for bit"
+    err = (outs[0] - ref).abs().max().item()
+    print("denoise %s %s max abs err %.3e (|ref| max %.2f)" % (sched_name, dtype, err, ref.abs().max()))
+    assert err <= (1e-2 if dtype == "fp32" else 1e-1)
+    tot, per = e.last_denoise_ms()
+    assert tot > 0 and per > 0
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_vae_and_vocoder(dtype):
+    """decode_first_stage + decode_to_waveform: full-size mel-VAE decoder and HiFi-GAN (B = 2)."""
+    shapes = W.vae_decoder_param_shapes(O.VAE_CONFIG)
+    shapes.update(W.hifigan_param_shapes(O.HIFIGAN_CONFIG))
+    sd = W.synth_state_dict(shapes, 1234)
+    e = Engine(vae=O.VAE_CONFIG, hifigan=O.HIFIGAN_CONFIG, dtype=dtype)
+    e.load_synthetic(1234)
+    g = torch.Generator().manual_seed(41)
+    z = torch.randn(2, 8, 256, 16, generator=g)
+    mel_ref = O.vae_decode_first_stage(sd, O.VAE_CONFIG, z)
+    mel = e.vae_decode(z.cuda())
+    assert mel.shape == (2, 1, 1024, 64)
+    err = relerr(mel.cpu(), mel_ref)
+    print("vae %s rel err %.3e" % (dtype, err))
+    assert err <= (1e-3 if dtype == "fp32" else 3e-2)
+    # vocoder on the ORACLE mel so the comparison isolates HiFi-GAN + int16 cast
+    wav_ref = O.decode_to_waveform(sd, O.HIFIGAN_CONFIG, mel_ref)
+    wav = e.vocode(mel_ref.cuda()).cpu().numpy()
+    assert wav.dtype == np.int16 and wav.shape == (2, 163872) == wav_ref.shape
+    d = np.abs(wav.astype(np.int32) - wav_ref.astype(np.int32))
+    frac1 = float((d <= 1).mean())
+    print("vocoder %s: |diff| max %d, <=1 LSB on %.4f, ref std %.0f" % (dtype, d.max(), frac1, wav_ref.std()))
+    if dtype == "fp32":
+        assert frac1 >= 0.999
+    else:
+        snr = 10 * np.log10((wav_ref.astype(np.float64) ** 2).mean() / ((d.astype(np.float64) ** 2).mean() + 1e-9))
+        print("vocoder fp16 SNR %.1f dB" % snr)
+        assert snr >= 30.0
+
+
+def test_generate_api_shapes():
+    """Tango.generate_from_embeddings: tiny UNet + real VAE/vocoder, 2 prompts, 3 steps, device Philox noise."""
+    from tango_amd.autoencoder import AutoencoderKL
+    from tango_amd.models import AudioDiffusion
+    from tango_amd.tango import Tango
+    model = AudioDiffusion(unet_config=O.UNET_CONFIG_TINY, dtype="fp16")
+    model.engine.load_synthetic(1234)
+    vae = AutoencoderKL(ddconfig=dict(O.VAE_CONFIG, resolution=256, in_channels=1, double_z=True, attn_resolutions=[], dropout=0.0),
+                        embed_dim=8, scale_factor=O.VAE_CONFIG["scale_factor"], dtype="fp16")
+    vae.engine.load_synthetic(1234)
+    t = Tango.from_components(model, vae)
+    enc, mask = text_inputs(4, 20, O.UNET_CONFIG_TINY["cross_attention_dim"], 51)
+    w1 = t.generate_from_embeddings(enc.cuda(), mask.cuda(), steps=3, guidance=3, seed=7)
+    w2 = t.generate_from_embeddings(enc.cuda(), mask.cuda(), steps=3, guidance=3, seed=7)
+    assert w1.dtype == np.int16 and w1.shape == (2, 163872)
+    assert np.array_equal(w1, w2), "same seed -> same audio"
+    assert vae.device().type == "cuda" and model.unet.config.in_channels == 8
+    with pytest.raises(ValueError):
+        t.scheduler.set_timesteps(1001)

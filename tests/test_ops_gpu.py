@@ -1,0 +1,202 @@
+"""Per-kernel parity: HIP op (through the C ABI) vs the fp32 torch CPU statement of the same op.
+Tolerances: fp32 engine rel-err <= 2e-5 of the output scale (f32 MFMA == fmaf chain); fp16 engine
+(fp16 operands, fp32 accumulate) <= 4e-3 of the output scale."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = {"fp32": 0, "fp16": 1, "bf16": 2}
+TOL = {"fp32": 2e-5, "fp16": 4e-3, "bf16": 3e-2}
+
+
+def dev(t):
+    return t.detach().float().contiguous().cuda()
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def check(lib, rc):
+    assert rc == 0, lib.tango_last_error().decode()
+
+
+def close(out, ref, dtype, what=""):
+    ref = ref.float().cpu()
+    out = out.float().cpu()
+    scale = ref.abs().max().item() + 1e-6
+    err = (out - ref).abs().max().item() / scale
+    assert err <= TOL[dtype], "%s: rel err %.3e > %.1e (scale %.3f)" % (what, err, TOL[dtype], scale)
+
+
+def quant(t, dtype):
+    """round operands to the engine storage dtype so the test isolates kernel arithmetic"""
+    if dtype == "fp16":
+        return t.half().float()
+    if dtype == "bf16":
+        return t.bfloat16().float()
+    return t
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(200, 320, 320), (128, 128, 64), (77, 48, 96), (300, 640, 1280), (64, 24, 32), (130, 8, 64)])
+def test_linear(lib, dtype, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = quant(torch.randn(M, K, generator=g), dtype)
+    w = quant(torch.randn(N, K, generator=g) / K ** 0.5, dtype)
+    b = torch.randn(N, generator=g)
+    r = quant(torch.randn(M, N, generator=g), dtype)
+    out = torch.empty(M, N, device="cuda")
+    check(lib, lib.tango_op_linear(DT[dtype], ptr(dev(x)), ptr(dev(w)), ptr(dev(b)), ptr(dev(r)), ptr(out), M, N, K, 0, 0, 0, None))
+    close(out, F.linear(x, w, b) + r, dtype, "linear")
+    # silu prologue + lrelu-free epilogue silu
+    check(lib, lib.tango_op_linear(DT[dtype], ptr(dev(x)), ptr(dev(w)), ptr(dev(b)), None, ptr(out), M, N, K, 1, 1, 0, None))
+    close(out, F.silu(F.linear(quant(F.silu(x), dtype), w, b)), dtype, "linear+silu")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_linear_geglu(lib, dtype):
+    M, C = 150, 64
+    g = torch.Generator().manual_seed(5)
+    x = quant(torch.randn(M, C, generator=g), dtype)
+    w = quant(torch.randn(8 * C, C, generator=g) / C ** 0.5, dtype)
+    b = torch.randn(8 * C, generator=g)
+    out = torch.empty(M, 4 * C, device="cuda")
+    check(lib, lib.tango_op_linear(DT[dtype], ptr(dev(x)), ptr(dev(w)), ptr(dev(b)), None, ptr(out), M, 8 * C, C, 0, 0, 1, None))
+    h = F.linear(x, w, b)
+    val, gate = h.chunk(2, dim=-1)
+    close(out, val * F.gelu(gate), dtype, "geglu")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("Cin,Cout,H,W,stride,ups", [(64, 64, 16, 8, 1, 0), (64, 96, 16, 8, 2, 0), (64, 32, 8, 4, 1, 1),
+                                                    (8, 64, 16, 16, 1, 0), (128, 160, 6, 2, 1, 0), (32, 8, 16, 4, 1, 0)])
+def test_conv2d(lib, dtype, Cin, Cout, H, W, stride, ups):
+    if dtype == "fp16" and (Cin * 2) % 64 and Cin != 8:
+        pytest.skip("Cin*2 bytes must be a 64-byte multiple")
+    B = 3
+    g = torch.Generator().manual_seed(Cin * Cout + H)
+    x = quant(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = quant(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5, dtype)
+    b = torch.randn(Cout, generator=g)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    ref = F.conv2d(xin, w, b, stride=stride, padding=1)
+    out = torch.empty(ref.shape, device="cuda")
+    check(lib, lib.tango_op_conv2d(DT[dtype], ptr(dev(x)), ptr(dev(w)), ptr(dev(b)), ptr(out), B, Cin, H, W, Cout, stride, ups, None))
+    close(out, ref, dtype, "conv2d")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("C,Co,L,k,d", [(32, 32, 301, 3, 1), (32, 32, 301, 7, 3), (64, 64, 200, 11, 5), (64, 128, 77, 7, 1), (32, 1, 500, 7, 1)])
+def test_conv1d(lib, dtype, C, Co, L, k, d):
+    B = 2
+    g = torch.Generator().manual_seed(C + L + k)
+    x = quant(torch.randn(B, C, L, generator=g), dtype)
+    w = quant(torch.randn(Co, C, k, generator=g) / (C * k) ** 0.5, dtype)
+    b = torch.randn(Co, generator=g)
+    r = quant(torch.randn(B, Co, L, generator=g), dtype)
+    ref = F.leaky_relu(F.conv1d(quant(F.leaky_relu(x, 0.1), dtype), w, b, dilation=d, padding=d * (k - 1) // 2), 0.1) + r
+    out = torch.empty(ref.shape, device="cuda")
+    check(lib, lib.tango_op_conv1d(DT[dtype], ptr(dev(x)), ptr(dev(w)), ptr(dev(b)), ptr(dev(r)), ptr(out), B, C, L, Co, k, d,
+                                   2, 0.1, 2, 0.1, None))
+    close(out, ref, dtype, "conv1d")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("Ci,Co,L,k,u", [(64, 32, 50, 16, 5), (64, 32, 53, 16, 4), (32, 32, 40, 8, 2), (64, 32, 31, 4, 2)])
+def test_conv_transpose1d(lib, dtype, Ci, Co, L, k, u):
+    B = 2
+    p = (k - u) // 2
+    g = torch.Generator().manual_seed(Ci + L + k)
+    x = quant(torch.randn(B, Ci, L, generator=g), dtype)
+    w = quant(torch.randn(Ci, Co, k, generator=g) / (Ci * k / u) ** 0.5, dtype)
+    b = torch.randn(Co, generator=g)
+    ref = F.conv_transpose1d(quant(F.leaky_relu(x, 0.1), dtype), w, b, stride=u, padding=p)
+    out = torch.empty(ref.shape, device="cuda")
+    check(lib, lib.tango_op_conv_transpose1d(DT[dtype], ptr(dev(x)), ptr(dev(w)), ptr(dev(b)), ptr(out), B, Ci, L, Co, k, u, p,
+                                             2, 0.1, None))
+    close(out, ref, dtype, "conv_transpose1d")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("C,HW,eps,act", [(320, 512, 1e-5, 1), (64, 4096, 1e-6, 0), (512, 100, 1e-6, 1), (2560, 64, 1e-5, 1), (1920, 33, 1e-5, 0), (128, 7000, 1e-6, 1)])
+def test_groupnorm(lib, dtype, C, HW, eps, act):
+    B = 3
+    g = torch.Generator().manual_seed(C + HW)
+    x = quant(torch.randn(B, C, HW, generator=g) * 1.7 + 0.4, dtype)
+    ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.group_norm(x, 32, ga, be, eps)
+    if act:
+        ref = F.silu(ref)
+    out = torch.empty(ref.shape, device="cuda")
+    check(lib, lib.tango_op_groupnorm(DT[dtype], ptr(dev(x)), ptr(dev(ga)), ptr(dev(be)), ptr(out), B, C, HW, 32, eps, act, None))
+    close(out, ref, dtype, "groupnorm")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("rows,C", [(100, 320), (37, 1280), (513, 64), (16, 640)])
+def test_layernorm(lib, dtype, rows, C):
+    g = torch.Generator().manual_seed(rows + C)
+    x = quant(torch.randn(rows, C, generator=g) * 2 - 0.3, dtype)
+    ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.layer_norm(x, (C,), ga, be, 1e-5)
+    out = torch.empty(ref.shape, device="cuda")
+    check(lib, lib.tango_op_layernorm(DT[dtype], ptr(dev(x)), ptr(dev(ga)), ptr(dev(be)), ptr(out), rows, C, 1e-5, None))
+    close(out, ref, dtype, "layernorm")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("B,heads,Sq,Skv,masked", [(2, 2, 256, 256, False), (2, 3, 64, 64, False), (3, 1, 200, 7, True),
+                                                   (2, 2, 1024, 64, True), (1, 5, 130, 130, False)])
+def test_attention(lib, dtype, B, heads, Sq, Skv, masked):
+    g = torch.Generator().manual_seed(Sq + Skv)
+    C_ = heads * 64
+    q = quant(torch.randn(B, Sq, C_, generator=g), dtype)
+    k = quant(torch.randn(B, Skv, C_, generator=g), dtype)
+    v = quant(torch.randn(B, Skv, C_, generator=g), dtype)
+    bias = None
+    if masked:
+        m = torch.ones(B, Skv)
+        m[0, 1:] = 0
+        if B > 1:
+            m[1, Skv // 2:] = 0
+        bias = (1 - m) * -10000.0
+    qh = q.view(B, Sq, heads, 64).transpose(1, 2)
+    kh = k.view(B, Skv, heads, 64).transpose(1, 2)
+    vh = v.view(B, Skv, heads, 64).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) * 0.125
+    if bias is not None:
+        s = s + bias[:, None, None, :]
+    ref = (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, Sq, C_)
+    out = torch.empty(ref.shape, device="cuda")
+    check(lib, lib.tango_op_attention(DT[dtype], ptr(dev(q)), ptr(dev(k)), ptr(dev(v)), ptr(dev(bias)) if bias is not None else None,
+                                      ptr(out), B, heads, Sq, Skv, 0.125, None))
+    close(out, ref, dtype, "attention")
+
+
+@pytest.mark.parametrize("pred", ["v_prediction", "epsilon"])
+def test_sched_step_bit_exact(lib, pred):
+    """fused CFG + DDPM step == oracle scheduler step, bit for bit (fp32, unfused mul/add order)."""
+    from oracle import tango_oracle as O
+    cfg = dict(O.SD21_SCHEDULER, prediction_type=pred)
+    sch = O.DDPMOracle(**cfg)
+    sch.set_timesteps(200)
+    B, Cc, HW = 2, 8, 4096
+    g = torch.Generator().manual_seed(3)
+    for t in (995, 500, 5, 0):
+        lat = torch.randn(B, Cc, 256, 16, generator=g)
+        mo = torch.randn(2 * B, Cc, 256, 16, generator=g)
+        nz = torch.randn(B, Cc, 256, 16, generator=g)
+        u, c = mo.chunk(2)
+        guided = u + 3.0 * (c - u)
+        ref = sch.step(guided, t, lat, noise=nz)
+        coef = np.asarray(sch.coefficients(t) + [0, 0, 0], dtype=np.float32)
+        lat_d = dev(lat)
+        check(lib, lib.tango_op_sched_step(ptr(lat_d), ptr(dev(mo)), ptr(dev(nz)), coef.ctypes.data_as(C.c_void_p), B, Cc, HW, 1, 3.0,
+                                           {"epsilon": 0, "v_prediction": 2}[pred], 0, 0, 1.0, None))
+        assert torch.equal(lat_d.cpu(), ref), "t=%d max diff %g" % (t, (lat_d.cpu() - ref).abs().max())
