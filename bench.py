@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the Tango hot path on MI355X (see BASELINE.json / DESIGN.md).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path over one batch per GPU: the CFG denoise loop
+(`--denoise-steps` UNet+scheduler iterations, default 200) -> mel-VAE decode -> HiFi-GAN -> int16, for
+`--batch` (default 32) synthetic 64-token prompts per GPU (BASELINE config 3: Tango-full, 200 steps,
+batch 32, guidance 3).  Inputs (text-encoder outputs, initial latents) are resident in HBM when the timed
+region starts; weights are seeded synthetic tensors of the real architecture (no checkpoint offline).
+Metric: audio-seconds generated per wall-second, whole job (all GPUs).  Weak scaling: per-GPU batch fixed.
+"""
+import argparse
+import json
+import os
+import platform
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+#: BASELINE.md section 2 (FlopCounterMode on the reference modules, 64 text tokens, CFG on)
+GFLOP_UNET_PER_PROMPT_STEP = 1606.36
+GFLOP_VAE_PER_SAMPLE = 670.47
+GFLOP_VOCODER_PER_SAMPLE = 1027.04
+AUDIO_SECONDS_PER_SAMPLE = 163872 / 16000.0
+PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1, help="timed passes of the hot path")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed passes")
+    ap.add_argument("--batch", type=int, default=32, help="prompts per GPU")
+    ap.add_argument("--denoise-steps", type=int, default=200)
+    ap.add_argument("--guidance", type=float, default=3.0)
+    ap.add_argument("--text-len", type=int, default=64)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
+    ap.add_argument("--xl", action="store_true", help="FLAN-T5-XL cross-attention width (2048)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1234)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, unet_cfg, vae_cfg, hifi_cfg, sched_cfg):
+    """The CPU oracle (fp32 restatement of the reference path, kind "port") timed on this host's cores on a
+    bounded sample: B = 1, 2 CFG denoise steps of the full UNet + 1 VAE decode + 1 vocode, extrapolated
+    linearly to `--denoise-steps`."""
+    from oracle import tango_oracle as O
+    from tango_amd import weights as W
+    threads = torch.get_num_threads()
+    usd = W.synth_state_dict(W.unet_param_shapes(unet_cfg, "unet."), args.seed)
+    shapes = W.vae_decoder_param_shapes(vae_cfg)
+    shapes.update(W.hifigan_param_shapes(hifi_cfg))
+    vsd = W.synth_state_dict(shapes, args.seed)
+    g = torch.Generator().manual_seed(0)
+    enc = torch.randn(2, args.text_len, unet_cfg["cross_attention_dim"], generator=g)
+    mask = torch.ones(2, args.text_len, dtype=torch.bool)
+    mask[0, 1:] = False
+    lat = torch.randn(1, 8, 256, 16, generator=g)
+    n = 2
+    sch = O.DDPMOracle(**sched_cfg)
+    with torch.no_grad():
+        O.unet_forward(usd, unet_cfg, torch.cat([lat] * 2), 999, enc, mask, prefix="unet.")   # page-in / thread-pool warm-up
+        t0 = time.time()
+        lat2 = O.denoise_loop(usd, unet_cfg, sch, enc, mask, lat, n, args.guidance, prefix="unet.")
+        t1 = time.time()
+        mel = O.vae_decode_first_stage(vsd, vae_cfg, lat2)
+        t2 = time.time()
+        O.decode_to_waveform(vsd, hifi_cfg, mel)
+        t3 = time.time()
+    t_step = (t1 - t0) / n
+    total = t_step * args.denoise_steps + (t2 - t1) + (t3 - t2)
+    return {
+        "value": AUDIO_SECONDS_PER_SAMPLE / total, "unit": "audio-seconds/s", "cores": threads, "kind": "port",
+        "sample": "B=1: %d full-UNet CFG steps (%.2f s/step) + VAE decode (%.2f s) + HiFi-GAN (%.2f s), fp32 torch CPU "
+                  "oracle, %d threads, %s; extrapolated linearly to %d steps"
+                  % (n, t_step, t2 - t1, t3 - t2, threads, platform.processor() or platform.machine(), args.denoise_steps),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from tango_amd.autoencoder import AutoencoderKL
+    from tango_amd.engine import HIFIGAN_CONFIG, UNET_CONFIG_LARGE, UNET_CONFIG_XL, VAE_CONFIG
+    from tango_amd.models import AudioDiffusion
+    from tango_amd.parallel import DataParallelGenerator
+    from tango_amd.scheduler import SD21_SCHEDULER_CONFIG
+    from tango_amd.tango import Tango
+
+    unet_cfg = UNET_CONFIG_XL if args.xl else UNET_CONFIG_LARGE
+    model = AudioDiffusion(unet_config=unet_cfg, dtype=args.dtype, device=device)
+    model.engine.load_synthetic(args.seed)
+    model.use_graph = not args.no_graph
+    vae = AutoencoderKL(ddconfig=dict(VAE_CONFIG, attn_resolutions=[]), embed_dim=8, scale_factor=VAE_CONFIG["scale_factor"],
+                        dtype=args.dtype, device=device)
+    vae.engine.load_synthetic(args.seed)
+    tango = Tango.from_components(model, vae)
+
+    B, L, d = args.batch, args.text_len, unet_cfg["cross_attention_dim"]
+    Bg = B * world
+    n_samples = vae.engine.vocoder_samples(1024)
+    denoise_ms = []
+
+    def compute(pe, pm, offset):
+        b = pe.shape[0] // 2
+        g = torch.Generator(device="cpu").manual_seed(1000 + offset)
+        lat = torch.randn(b, 8, 256, 16, generator=g).to(device)
+        latents = model.inference_from_embeddings(pe, pm, tango.scheduler, args.denoise_steps, args.guidance, latents=lat,
+                                                  seed=args.seed, sample_offset=offset)
+        mel = vae.decode_first_stage(latents)
+        wav = vae.engine.vocode(mel)            # int16 stays on the device; the gather moves it
+        denoise_ms.append(model.engine.last_denoise_ms())
+        return wav.cpu().numpy()
+
+    dp = DataParallelGenerator(compute, device)
+    pe = pm = None
+    if rank == 0:   # synthetic text-encoder outputs: [uncond; cond], uncond mask = [1, 0, ...]
+        g = torch.Generator().manual_seed(7)
+        cond = torch.randn(Bg, L, d, generator=g)
+        unc = torch.randn(Bg, L, d, generator=g)
+        pe = torch.cat([unc, cond]).to(device)
+        mc = torch.ones(Bg, L, dtype=torch.bool)
+        mu = torch.zeros(Bg, L, dtype=torch.bool)
+        mu[:, 0] = True
+        pm = torch.cat([mu, mc]).to(device)
+
+    def one_pass():
+        return dp.generate(pe, pm, args.guidance, n_samples)
+
+    for _ in range(args.warmup):
+        one_pass()
+    denoise_ms.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wav = one_pass()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        assert wav.shape == (Bg, n_samples) and wav.dtype == np.int16
+        audio_s = Bg * AUDIO_SECONDS_PER_SAMPLE * args.steps
+        per_step_ms = float(np.mean([m[1] for m in denoise_ms])) if denoise_ms else float("nan")
+        # roofline of the dominant launch = one hipGraph replay of the UNet step (MFMA-bound):
+        # algorithmic 1606.36 GFLOP per (prompt, step) x B prompts per launch / measured launch duration
+        ach = GFLOP_UNET_PER_PROMPT_STEP * B / per_step_ms   # GFLOP / ms == TFLOP/s
+        out = {
+            "metric": "audio-seconds generated/sec, Tango-full %d-step, batch=%d, guidance=%g" % (args.denoise_steps, B, args.guidance),
+            "value": audio_s / dt, "unit": "audio-seconds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic (seeded random weights of the real architecture; N(0,1) text embeddings)",
+            "config": {"workload": "BASELINE config 3: Tango-full%s UNet (866M) %d-step DDPM CFG=%g denoise + mel-VAE decode + "
+                                   "HiFi-GAN, %d prompts/GPU x %d tokens" % (" XL" if args.xl else "", args.denoise_steps, args.guidance, B, L),
+                       "global_batch": Bg, "text_len": L, "denoise_steps": args.denoise_steps, "parallelism": "dp%d" % world,
+                       "hipgraph": not args.no_graph},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                         "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": None,
+                         "kernel": "UNet denoise step (one hipGraph replay = %d prompts x 1606.36 GFLOP), %.2f ms/launch by HIP events"
+                                   % (B, per_step_ms)},
+            "end_to_end_tflops": (GFLOP_UNET_PER_PROMPT_STEP * args.denoise_steps + GFLOP_VAE_PER_SAMPLE + GFLOP_VOCODER_PER_SAMPLE)
+                                 * Bg * args.steps / dt / 1000.0,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            keys = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "prediction_type", "clip_sample", "variance_type")
+            out["cpu_baseline"] = cpu_baseline(args, unet_cfg, VAE_CONFIG, HIFIGAN_CONFIG, {k: SD21_SCHEDULER_CONFIG[k] for k in keys})
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,8 +14,21 @@ DT = {"fp32": 0, "fp16": 1, "bf16": 2}
 TOL = {"fp32": 2e-5, "fp16": 4e-3, "bf16": 3e-2}
 
 
+_KEEP = []
+
+
 def dev(t):
-    return t.detach().float().contiguous().cuda()
+    """device copy that stays alive until the next test (raw pointers are handed to the C ABI)"""
+    d = t.detach().float().contiguous().cuda()
+    _KEEP.append(d)
+    return d
+
+
+@pytest.fixture(autouse=True)
+def _clear_keep():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
 
 
 def ptr(t):
