@@ -81,8 +81,11 @@ class DataParallelGenerator:
         bmax = (B + self.world - 1) // self.world
         buf = torch.zeros((bmax, n_samples), dtype=torch.int16, device=self.device)
         buf[:b_local] = torch.from_numpy(wav).to(self.device)
-        outs = [torch.empty_like(buf) for _ in range(self.world)] if self.rank == 0 else None
-        dist.gather(buf, outs, dst=0, group=self.group)
+        # neither RCCL nor gloo has an int16 datatype: ship the waveform bytes
+        raw = buf.view(torch.uint8)
+        outs8 = [torch.empty_like(raw) for _ in range(self.world)] if self.rank == 0 else None
+        dist.gather(raw, outs8, dst=0, group=self.group)
+        outs = [o.view(torch.int16) for o in outs8] if self.rank == 0 else None
         if self.rank != 0:
             return None
         parts: List[np.ndarray] = []

@@ -1,0 +1,119 @@
+"""Host-side logic that needs no GPU: parameter inventories, synthetic weights, sharding, C-ABI exports,
+error behaviour mirrored from the reference."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tango_amd import _lib, weights as W
+from tango_amd.engine import HIFIGAN_CONFIG, UNET_CONFIG_LARGE, UNET_CONFIG_XL, VAE_CONFIG
+from tango_amd.parallel import shard_bounds, shard_cfg_embeddings
+from tango_amd.scheduler import SD21_SCHEDULER_CONFIG, DDIMScheduler, DDPMScheduler
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_param_inventory_counts():
+    """686 UNet tensors, 865 933 768 UNet parameters; 308 decode-side VAE+vocoder tensors"""
+    u = W.unet_param_shapes(UNET_CONFIG_LARGE)
+    assert len(u) == 686
+    assert sum(int(np.prod(s)) for s in u.values()) == 865933768
+    v = W.vae_decoder_param_shapes(VAE_CONFIG)
+    h = W.hifigan_param_shapes(HIFIGAN_CONFIG)
+    assert len(v) + len(h) == 308
+    assert sum(int(np.prod(s)) for s in h.values()) == 55264897
+    assert u["up_blocks.1.resnets.2.conv1.weight"] == (1280, 1920, 3, 3)
+    assert W.unet_param_shapes(UNET_CONFIG_XL)["mid_block.attentions.0.transformer_blocks.0.attn2.to_k.weight"] == (1280, 2048)
+    assert h["vocoder.ups.0.weight"] == (1024, 512, 16)
+
+
+def test_synth_weights_deterministic_and_independent():
+    a = W.synth_tensor("unet.conv_in.weight", (320, 8, 3, 3), 1234)
+    b = W.synth_tensor("unet.conv_in.weight", (320, 8, 3, 3), 1234)
+    c = W.synth_tensor("unet.conv_in.weight", (320, 8, 3, 3), 1235)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert abs(a.abs().max().item() - 1 / 72 ** 0.5) < 1e-3
+    g = W.synth_tensor("decoder.norm_out.weight", (128,), 1)
+    assert abs(g.mean().item() - 1.0) < 0.1
+
+
+def test_library_exports_every_declared_symbol():
+    """the C ABI library loads without a GPU and exports every function include/tango_engine.h declares"""
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "tango_engine.h")).read()
+    declared = set(re.findall(r"\b(tango_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"tango_engine_t", "tango_config_t", "tango_denoise_args_t"}
+    assert declared, "header parse"
+    for s in declared:
+        assert hasattr(lib, s), "libtango_hip.so does not export %s" % s
+    assert set(_lib.SYMBOLS) == declared
+    assert lib.tango_version().decode().startswith("tango-mi355x")
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only check")
+def test_engine_fails_loudly_without_gpu():
+    """no CPU fallback: creating an engine without a HIP device raises"""
+    from tango_amd.engine import Engine
+    with pytest.raises(RuntimeError):
+        Engine(unet=UNET_CONFIG_LARGE)
+    import ctypes as C
+    lib = _lib.load()
+    cfg = _lib.TangoConfig()
+    h = C.c_void_p()
+    assert lib.tango_engine_create(C.byref(cfg), C.byref(h)) != 0
+    assert b"no HIP device" in lib.tango_last_error() or b"fail" in lib.tango_last_error().lower()
+
+
+def test_product_tree_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tango_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in re.sub(r'"""[\s\S]*?"""', "", src), "%s references oracle/" % f
+
+
+def test_shard_bounds_cover_and_order():
+    for n in (1, 7, 32, 33, 256):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_shard_cfg_keeps_uncond_twin():
+    B, L, d = 5, 3, 4
+    pe = torch.arange(2 * B).float()[:, None, None].expand(2 * B, L, d).contiguous()
+    pm = torch.ones(2 * B, L, dtype=torch.bool)
+    seen = []
+    for r in range(2):
+        e, m, lo = shard_cfg_embeddings(pe, pm, 2, r, True)
+        b = e.shape[0] // 2
+        assert e[:b, 0, 0].tolist() == [float(lo + i) for i in range(b)]            # uncond rows
+        assert e[b:, 0, 0].tolist() == [float(B + lo + i) for i in range(b)]        # matching cond rows
+        seen += list(range(lo, lo + b))
+    assert seen == list(range(B))
+
+
+def test_scheduler_surface_and_errors():
+    keys = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "prediction_type", "clip_sample", "variance_type")
+    s = DDPMScheduler.from_config({k: SD21_SCHEDULER_CONFIG[k] for k in keys})
+    assert s.order == 1 and s.init_noise_sigma == 1.0 and s.config.prediction_type == "v_prediction"
+    x = torch.ones(2)
+    assert s.scale_model_input(x, 5) is x
+    s.set_timesteps(200)
+    assert s.timesteps.tolist() == list(range(995, -1, -5))
+    with pytest.raises(ValueError):              # scheduling_ddpm.py:193-198
+        s.set_timesteps(1001)
+    with pytest.raises(ValueError):              # scheduling_ddpm.py:305-309
+        DDPMScheduler(prediction_type="bogus")
+    t = s.coef_table()
+    assert t.shape == (200, 8) and t.dtype == np.float32
+    assert t[-1, 2] == 1.0 and t[-1, 3] == 0.0 and t[-1, 4] == 0.0      # last step: abar_prev = 1, no noise
+    d = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                      prediction_type="v_prediction", clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    d.set_timesteps(200)
+    assert d.timesteps.tolist() == list(range(996, 0, -5)) and d.rule == "ddim"

@@ -1,0 +1,286 @@
+"""Pins the CPU oracle (oracle/tango_oracle.py) to the reference: the fork's own known-answer tests and
+the fixtures generated from the imported reference modules (oracle/make_golden.py).  CPU only."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tango_oracle as O
+from tango_amd import weights as W
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+torch.set_grad_enabled(False)
+
+
+def checksum(t):
+    a = t.detach().double()
+    return np.asarray([float(a.sum()), float(a.abs().sum()), float((a * a).sum())])
+
+
+# ---------------------------------------------------------------- schedulers
+def _deter_sample():
+    # tests/schedulers/test_schedulers.py:222-234
+    n = 4 * 3 * 8 * 8
+    s = torch.arange(n).reshape(3, 8, 8, 4) / n
+    return s.permute(3, 0, 1, 2)
+
+
+def _model(sample, t):
+    return sample * t / (t + 1)
+
+
+@pytest.mark.parametrize("pred,exp_sum,exp_mean", [("epsilon", 258.9606, 0.3372), ("v_prediction", 202.0296, 0.2631)])
+def test_ddpm_full_loop_kat(pred, exp_sum, exp_mean):
+    """mustango/diffusers/tests/schedulers/test_scheduler_ddpm.py:71-131"""
+    sch = O.DDPMOracle(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                       variance_type="fixed_small", clip_sample=True, prediction_type=pred)
+    sample = _deter_sample()
+    gen = torch.manual_seed(0)
+    for t in reversed(range(1000)):
+        sample = sch.step(_model(sample, t), t, sample, generator=gen)
+    assert abs(sample.abs().sum().item() - exp_sum) < 1e-2
+    assert abs(sample.abs().mean().item() - exp_mean) < 1e-3
+
+
+def test_ddpm_variance_kat():
+    """test_scheduler_ddpm.py:62-69"""
+    sch = O.DDPMOracle(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                       variance_type="fixed_small", clip_sample=True)
+    assert abs(sch.variance(0) - 0.0) < 1e-5
+    assert abs(sch.variance(487) - 0.00979) < 1e-5
+    assert abs(sch.variance(999) - 0.02) < 1e-5
+
+
+@pytest.mark.parametrize("kw,exp_sum,exp_mean", [
+    (dict(), 172.0067, 0.223967), (dict(prediction_type="v_prediction"), 52.5302, 0.0684),
+    (dict(set_alpha_to_one=True, beta_start=0.01), 149.8295, 0.1951), (dict(set_alpha_to_one=False, beta_start=0.01), 149.0784, 0.1941)])
+def test_ddim_full_loop_kat(kw, exp_sum, exp_mean):
+    """mustango/diffusers/tests/schedulers/test_scheduler_ddim.py:24-41,106-140"""
+    cfg = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", clip_sample=True)
+    cfg.update(kw)
+    sch = O.DDIMOracle(**cfg)
+    sch.set_timesteps(10)
+    sample = _deter_sample()
+    for t in sch.timesteps:
+        sample = sch.step(_model(sample, t), t, sample, eta=0.0)
+    assert abs(sample.abs().sum().item() - exp_sum) < 1e-2
+    assert abs(sample.abs().mean().item() - exp_mean) < 1e-3
+
+
+def test_ddim_steps_offset_kat():
+    """test_scheduler_ddim.py:46-54"""
+    sch = O.DDIMOracle(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", steps_offset=1)
+    sch.set_timesteps(5)
+    assert sch.timesteps.tolist() == [801, 601, 401, 201, 1]
+
+
+def test_scheduler_tables_match_reference_bit_exact():
+    """fork DDPMScheduler with the SD-2.1 config (fixture) == oracle == product host scheduler, exactly."""
+    from tango_amd.scheduler import DDPMScheduler
+    g = json.load(open(os.path.join(G, "scheduler_sd21.json")))
+    cfg = g["config"]
+    o = O.DDPMOracle(**cfg)
+    assert [float(o.betas[0]), float(o.betas[999])] == g["betas"]
+    for i, v in g["alphas_cumprod"].items():
+        assert float(o.alphas_cumprod[int(i)]) == v
+    assert g["timesteps"]["200"][:3] == [995, 990, 985] and g["timesteps"]["200"][-1] == 0
+    assert g["timesteps"]["100"][:2] == [990, 980] and g["timesteps"]["10"] == [900, 800, 700, 600, 500, 400, 300, 200, 100, 0]
+    for n, ts in g["timesteps"].items():
+        o = O.DDPMOracle(**cfg)
+        o.set_timesteps(int(n))
+        p = DDPMScheduler.from_config(cfg)
+        p.set_timesteps(int(n))
+        assert o.timesteps.tolist() == ts == p.timesteps.tolist()          # integer schedule: bit-exact
+        assert p.timesteps.dtype == torch.int64
+        table = p.coef_table()
+        for t, row in g["coef"][n].items():
+            assert o.coefficients(int(t)) == row, (n, t)
+            i = ts.index(int(t))
+            assert table[i, :5].tolist() == np.asarray(row, np.float32).tolist(), (n, t)
+    assert g["ddim_offset1_5"] == [801, 601, 401, 201, 1]
+    # SURVEY.md Appendix E spot values
+    assert abs(g["coef"]["200"]["995"][0] - 0.06992948055267334) < 1e-12
+
+
+def test_sinusoid_kat():
+    """tests/test_layers_utils.py:92-112, variant t2 (flip_sin_to_cos=True, shift 0 == Tango's setting)"""
+    t2 = O.timestep_embedding(torch.arange(128), 64, True, 0)
+    exp = torch.tensor([0.3019, 0.2280, 0.1716, 0.3146, 0.2377, 0.1790, 0.3272, 0.2474, 0.1864])
+    assert torch.allclose(t2[23:26, 47:50].flatten(), exp, 1e-3)
+
+
+# ---------------------------------------------------------------- block / layer KATs
+@pytest.fixture(scope="module")
+def kat():
+    z = np.load(os.path.join(G, "kat_blocks.npz"))
+    out = {}
+    for k in z.files:
+        name, key = k.split("/", 1)
+        out.setdefault(name, {})[key] = torch.from_numpy(z[k])
+    return out
+
+
+def _harness_inputs(up=False):
+    torch.manual_seed(0)
+    hs = torch.randn(4, 32, 32, 32)
+    temb = torch.randn(4, 128)
+    res = None
+    if up:
+        torch.manual_seed(1)
+        res = torch.randn(4, 32, 32, 32)
+    return hs, temb, res
+
+
+def _squeeze_proj(sd, p):
+    """the KAT blocks use conv proj_in/out (use_linear_projection=False); same math as the linear form"""
+    sd = dict(sd)
+    for n in ("proj_in", "proj_out"):
+        k = "%s.%s.weight" % (p, n)
+        sd[k] = sd[k].reshape(sd[k].shape[0], sd[k].shape[1])
+    return sd
+
+
+def _check(out, ref, tol=5e-3):
+    sl = out[0, -1, -3:, -3:].flatten()
+    assert torch.allclose(sl, ref["expected_slice"], atol=tol), (sl, ref["expected_slice"])
+    assert np.allclose(checksum(out), ref["out_checksum"].numpy(), rtol=1e-4, atol=1e-2)
+
+
+def test_kat_downblock2d(kat):
+    """tests/test_unet_2d_blocks.py:23-30"""
+    sd = kat["DownBlock2D"]
+    hs, temb, _ = _harness_inputs()
+    h = O.resnet_block_2d(sd, "resnets.0", hs, temb, 32, 1e-6)
+    h = torch.nn.functional.conv2d(h, sd["downsamplers.0.conv.weight"], sd["downsamplers.0.conv.bias"], stride=2, padding=1)
+    _check(h, sd)
+
+
+def test_kat_crossattn_downblock2d(kat):
+    """tests/test_unet_2d_blocks.py:50-61 (no encoder states: attn2 attends to the hidden states)"""
+    sd = _squeeze_proj(kat["CrossAttnDownBlock2D"], "attentions.0")
+    hs, temb, _ = _harness_inputs()
+    h = O.resnet_block_2d(sd, "resnets.0", hs, temb, 32, 1e-6)
+    h = O.transformer_2d(sd, "attentions.0", h, 1, None, None, 32)
+    h = torch.nn.functional.conv2d(h, sd["downsamplers.0.conv.weight"], sd["downsamplers.0.conv.bias"], stride=2, padding=1)
+    _check(h, sd)
+
+
+def test_kat_midblock_crossattn(kat):
+    """tests/test_unet_2d_blocks.py:168-179"""
+    sd = _squeeze_proj(kat["UNetMidBlock2DCrossAttn"], "attentions.0")
+    hs, temb, _ = _harness_inputs()
+    h = O.resnet_block_2d(sd, "resnets.0", hs, temb, 32, 1e-6)
+    h = O.transformer_2d(sd, "attentions.0", h, 1, None, None, 32)
+    h = O.resnet_block_2d(sd, "resnets.1", h, temb, 32, 1e-6)
+    _check(h, sd)
+
+
+def test_kat_upblock2d(kat):
+    """tests/test_unet_2d_blocks.py:200-210"""
+    sd = kat["UpBlock2D"]
+    hs, temb, res = _harness_inputs(up=True)
+    h = O.resnet_block_2d(sd, "resnets.0", torch.cat([hs, res], 1), temb, 32, 1e-6)
+    h = torch.nn.functional.interpolate(h, scale_factor=2.0, mode="nearest")
+    h = torch.nn.functional.conv2d(h, sd["upsamplers.0.conv.weight"], sd["upsamplers.0.conv.bias"], padding=1)
+    _check(h, sd)
+
+
+def test_kat_crossattn_upblock2d(kat):
+    """tests/test_unet_2d_blocks.py:226-241"""
+    sd = _squeeze_proj(kat["CrossAttnUpBlock2D"], "attentions.0")
+    hs, temb, res = _harness_inputs(up=True)
+    h = O.resnet_block_2d(sd, "resnets.0", torch.cat([hs, res], 1), temb, 32, 1e-6)
+    h = O.transformer_2d(sd, "attentions.0", h, 1, None, None, 32)
+    h = torch.nn.functional.interpolate(h, scale_factor=2.0, mode="nearest")
+    h = torch.nn.functional.conv2d(h, sd["upsamplers.0.conv.weight"], sd["upsamplers.0.conv.bias"], padding=1)
+    _check(h, sd)
+
+
+def test_kat_resnetblock2d(kat):
+    """tests/test_layers_utils.py:225-239"""
+    sd = kat["ResnetBlock2D"]
+    torch.manual_seed(0)
+    sample, temb = torch.randn(1, 32, 64, 64), torch.randn(1, 128)
+    out = O.resnet_block_2d(sd, "", sample, temb, 32, 1e-6) if False else O.resnet_block_2d({("x." + k): v for k, v in sd.items()}, "x", sample, temb, 32, 1e-6)
+    _check(out, sd, 1e-3)
+
+
+def test_kat_transformer2d_cross_attention(kat):
+    """tests/test_layers_utils.py:395-418"""
+    sd = _squeeze_proj({("x." + k): v for k, v in kat["Transformer2DModel"].items()}, "x")
+    torch.manual_seed(0)
+    sample = torch.randn(1, 64, 64, 64)
+    out = O.transformer_2d(sd, "x", sample, 2, sd["x.context"], None, 32)
+    ref = kat["Transformer2DModel"]
+    sl = out[0, -1, -3:, -3:].flatten()
+    assert torch.allclose(sl, ref["expected_slice"], atol=1e-3)
+    assert np.allclose(checksum(out), ref["out_checksum"].numpy(), rtol=1e-4, atol=1e-2)
+
+
+# ---------------------------------------------------------------- differential fixtures (reference outputs)
+def _unet_inputs(cfg, B2, L, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B2, 8, 256, 16, generator=g)
+    enc = torch.randn(B2, L, cfg["cross_attention_dim"], generator=g)
+    mask = torch.ones(B2, L, dtype=torch.bool)
+    mask[0, 1:] = False
+    if B2 > 2:
+        mask[2, L // 2:] = False
+    return x, enc, mask
+
+
+@pytest.mark.parametrize("name", ["tiny", "large"])
+def test_unet_matches_reference_fixture(name):
+    """fork UNet2DConditionModel (masked cross-attention path) vs the oracle, same seeded weights/inputs"""
+    z = np.load(os.path.join(G, "unet_ref.npz"))
+    cfg = {"tiny": O.UNET_CONFIG_TINY, "large": O.UNET_CONFIG_LARGE}[name]
+    B2, L, t, seed = [int(v) for v in z[name + "/meta"]]
+    sd = W.synth_state_dict(W.unet_param_shapes(cfg), 1234)
+    x, enc, mask = _unet_inputs(cfg, B2, L, seed)
+    out = O.unet_forward(sd, cfg, x, t, enc, mask)
+    assert np.abs(out[:, :, ::37, ::5].numpy() - z[name + "/slice"]).max() < 2e-5
+    assert np.allclose(checksum(out), z[name + "/checksum"], rtol=1e-5, atol=1e-2)
+
+
+def test_denoise_loop_matches_reference_fixture():
+    """models.py:224-249 run with the fork UNet + fork DDPMScheduler and the GLOBAL torch RNG (draw order:
+    latents, then one randn per step with t > 0) vs oracle.denoise_loop fed the same draws"""
+    z = np.load(os.path.join(G, "loop_ref.npz"))
+    B, L, N, seed, iseed = [int(v) for v in z["meta"]]
+    cfg = O.UNET_CONFIG_TINY
+    sd = W.synth_state_dict(W.unet_param_shapes(cfg), 1234)
+    _, enc, mask = _unet_inputs(cfg, 2 * B, L, iseed)
+    torch.manual_seed(seed)
+    lat = torch.randn(B, 8, 256, 16)
+    sch = O.DDPMOracle(**O.SD21_SCHEDULER)
+    sch.set_timesteps(N)
+    noises = [torch.randn(B, 8, 256, 16) if int(t) > 0 else None for t in sch.timesteps]
+    out = O.denoise_loop(sd, cfg, sch, enc, mask, lat, N, 3.0, noises=noises)
+    assert np.abs(out[:, :, ::37, ::5].numpy() - z["slice"]).max() < 5e-5
+    assert np.allclose(checksum(out), z["checksum"], rtol=1e-5, atol=1e-2)
+
+
+def test_vae_vocoder_match_reference_fixture():
+    """AutoencoderKL.decode_first_stage / decode_to_waveform of the reference vs the oracle (int16 exact)"""
+    z = np.load(os.path.join(G, "vae_voc_ref.npz"))
+    shapes = W.vae_decoder_param_shapes(O.VAE_CONFIG)
+    shapes.update(W.hifigan_param_shapes(O.HIFIGAN_CONFIG))
+    sd = W.synth_state_dict(shapes, 1234)
+    g = torch.Generator().manual_seed(41)
+    lat = torch.randn(2, 8, 256, 16, generator=g)
+    mel = O.vae_decode_first_stage(sd, O.VAE_CONFIG, lat)
+    assert mel.shape == (2, 1, 1024, 64)
+    assert np.abs(mel[:, 0, ::41, ::3].numpy() - z["mel_slice"]).max() < 1e-5
+    wav = O.decode_to_waveform(sd, O.HIFIGAN_CONFIG, mel)
+    assert wav.dtype == np.int16 and wav.shape == (2, 163872)
+    assert np.array_equal(wav[:, :4096], z["wav_head"]) and np.array_equal(wav[:, -4096:], z["wav_tail"])
+    assert zlib.crc32(wav.tobytes()) == int(z["wav_crc"][0])
+
+
+def test_int16_cast_semantics():
+    """hifigan/utilities.py:81: truncation toward zero; +1.0 * 32768 wraps to -32768 (x86 numpy)"""
+    w = torch.tensor([[0.99999, -0.99999, 0.5 / 32768, -0.5 / 32768, 1.5 / 32768, -1.5 / 32768, -1.0]])
+    assert O.wav_to_int16(w).tolist() == [[32767, -32767, 0, 0, 1, -1, -32768]]

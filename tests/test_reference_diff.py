@@ -1,0 +1,61 @@
+"""Live differential tests against the imported reference (build container only; skipped on the GPU box,
+where /root/reference does not exist -- the committed fixtures in tests/golden/ carry the same evidence)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_import as R
+from oracle import tango_oracle as O
+from tango_amd import weights as W
+
+pytestmark = [pytest.mark.reference, pytest.mark.skipif(not R.available(), reason="/root/reference not present")]
+torch.set_grad_enabled(False)
+
+
+def test_param_inventories_match_reference_state_dicts():
+    with torch.device("meta"):
+        unet = R.unet_cls()(**R.unet_config())
+    ref = {k: tuple(v.shape) for k, v in unet.state_dict().items()}
+    assert ref == {k: tuple(v) for k, v in W.unet_param_shapes(O.UNET_CONFIG_LARGE).items()}
+    vae = R.autoencoder_cls()(**R.vae_config())
+    ref = {k: tuple(v.shape) for k, v in vae.state_dict().items() if not k.startswith(("encoder", "quant_conv"))}
+    mine = dict(W.vae_decoder_param_shapes(O.VAE_CONFIG))
+    mine.update(W.hifigan_param_shapes(O.HIFIGAN_CONFIG))
+    assert ref == {k: tuple(v) for k, v in mine.items()}
+
+
+def test_unet_tiny_matches_fork_with_ragged_mask():
+    cfgo = O.UNET_CONFIG_TINY
+    cfg = dict(R.unet_config())
+    cfg.update({k: cfgo[k] for k in ("block_out_channels", "attention_head_dim", "cross_attention_dim")})
+    sd = W.synth_state_dict(W.unet_param_shapes(cfgo), 7)
+    unet = R.unet_cls()(**cfg).eval()
+    unet.load_state_dict(sd)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 8, 256, 16, generator=g)
+    enc = torch.randn(3, 11, cfgo["cross_attention_dim"], generator=g)
+    mask = torch.ones(3, 11, dtype=torch.bool)
+    mask[0, 1:] = False
+    mask[2, 4:] = False
+    ref = unet(x, torch.tensor(123), encoder_hidden_states=enc, encoder_attention_mask=mask).sample
+    out = O.unet_forward(sd, cfgo, x, 123, enc, mask)
+    assert (ref - out).abs().max().item() < 2e-5
+    # perturbing masked text tokens must not change the output (exp(-10000) == 0 in fp32)
+    enc2 = enc.clone()
+    enc2[2, 4:] += 5.0
+    assert torch.equal(O.unet_forward(sd, cfgo, x, 123, enc2, mask), out)
+
+
+def test_scheduler_step_matches_fork_bitwise():
+    D = R.ddpm_cls()
+    cfg = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+               prediction_type="v_prediction", clip_sample=False, variance_type="fixed_small")
+    a, b = D(**cfg), O.DDPMOracle(**cfg)
+    a.set_timesteps(200)
+    b.set_timesteps(200)
+    g = torch.Generator().manual_seed(0)
+    x, v = torch.randn(2, 8, 256, 16, generator=g), torch.randn(2, 8, 256, 16, generator=g)
+    for t in (995, 500, 5, 0):
+        ra = a.step(v, t, x, generator=torch.Generator().manual_seed(9)).prev_sample
+        rb = b.step(v, t, x, generator=torch.Generator().manual_seed(9))
+        assert torch.equal(ra, rb)
