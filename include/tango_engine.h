@@ -135,6 +135,10 @@ int tango_engine_vocoder_samples(tango_engine_t* h, int mel_frames);
 /* timing of the last denoise call's kernels, measured with HIP events on the launch stream */
 int tango_engine_last_denoise_ms(tango_engine_t* h, float* total_ms, float* per_step_ms);
 
+/* diagnostic: eager run of one UNet step with HIP events around every kernel group; writes
+ * "label<TAB>ms<TAB>GFLOP" lines into `report` (truncated to report_cap). */
+int tango_engine_profile_unet(tango_engine_t* h, int batch2, int text_len, char* report, int report_cap, void* stream);
+
 /* ---- per-operator entry points (parity tests; fp32 reference-layout tensors on device) ---- */
 int tango_op_conv2d(int dtype, const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
                     int Cout, int stride, int upsample, void* stream);

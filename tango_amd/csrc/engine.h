@@ -16,10 +16,14 @@ using Op = std::function<int(hipStream_t)>;
 
 struct Program {
   std::vector<Op> ops;
+  std::vector<std::string> labels;   // parallel to ops (per-op profiling)
+  std::vector<double> flops;
   int run(hipStream_t s) const {
     for (const auto& o : ops) TANGO_TRY(o(s));
     return 0;
   }
+  // eager run with HIP events around every op; appends "label<TAB>ms<TAB>gflop" lines to `report`
+  int run_profiled(hipStream_t s, std::string& report) const;
 };
 
 // bump allocator over one hipMalloc'd slab; build is run twice (measure, then real)
@@ -133,6 +137,7 @@ class Engine {
   int vocode(const float* mel, int16_t* wav, int B, int frames, int* n_samples, hipStream_t s);
   int vocoder_samples(int frames) const;
   int last_denoise_ms(float* total_ms, float* per_step_ms);
+  int profile_unet(int B2, int L, std::string& report, hipStream_t s);
 
   tango_config_t cfg;
   int dt = DT_F32;

@@ -56,12 +56,19 @@ struct Builder {
     r.C = C;
     return r;
   }
-  void push(Op op) {
-    if (record) prog->ops.push_back(std::move(op));
+  std::string scope;   // label prefix of the module being built
+  void push(Op op, const std::string& label = "op", double fl = 0.0) {
+    if (record) {
+      prog->ops.push_back(std::move(op));
+      prog->labels.push_back(scope + label);
+      prog->flops.push_back(fl);
+    }
   }
-  void gemm(const GemmParams& p) {
+  void gemm(const GemmParams& p, const char* what = "gemm") {
     const int d = dt;
-    push([p, d](hipStream_t s) { return launch_gemm(d, p, s); });
+    char buf[160];
+    snprintf(buf, sizeof buf, "%s M=%d N=%d K=%d%s", what, p.M, p.N, p.K, p.batch > 1 ? " batched" : "");
+    push([p, d](hipStream_t s) { return launch_gemm(d, p, s); }, buf, 2.0 * p.M * (double)p.N * p.K * p.batch);
   }
 
 
@@ -76,7 +83,7 @@ struct Builder {
     if (o.residual) { p.R = o.residual->p; p.ldr = o.residual->ld; }
     p.a_act = o.a_act; p.a_slope = o.a_slope; p.e_act = o.e_act; p.e_slope = o.e_slope; p.epi = o.epi;
     p.bias2 = o.bias2; p.bias2_stride = o.bias2_stride; p.step_ptr = o.bias2 ? E.d_step : nullptr;
-    gemm(p);
+    gemm(p, "linear");
   }
 
   // 3x3 conv (pad 1) on NHWC: output grid B x H x W; source B x Hin x Win (nearest-upsampled x2 when ups)
@@ -102,7 +109,7 @@ struct Builder {
     if (o.residual) { p.R = o.residual->p; p.ldr = o.residual->ld; }
     p.a_act = o.a_act; p.a_slope = o.a_slope; p.e_act = o.e_act; p.e_slope = o.e_slope; p.epi = o.epi;
     p.bias2 = o.bias2; p.bias2_stride = o.bias2_stride; p.step_ptr = o.bias2 ? E.d_step : nullptr;
-    gemm(p);
+    gemm(p, stride == 2 ? "conv3x3s2" : (ups ? "conv3x3up" : "conv3x3"));
   }
 
   void groupnorm(const TView& x, int B, int rows, const WNorm& w, int groups, int act, const TView& out) {
@@ -115,7 +122,7 @@ struct Builder {
     p.partial = ws;
     p.scale_shift = ws + (nf - (size_t)B * w.C * 2);
     const int d = dt;
-    push([p, d](hipStream_t s) { return launch_groupnorm(d, p, s); });
+    push([p, d](hipStream_t s) { return launch_groupnorm(d, p, s); }, "groupnorm C=" + std::to_string(w.C) + " rows=" + std::to_string(rows));
     // NOTE: the workspace is released immediately; the next allocation may alias it, which is
     // safe because the whole program is serialized on one stream.
     A.release(m);
@@ -125,7 +132,7 @@ struct Builder {
     const int d = dt;
     const void* xp = x.p; const int64_t ldx = x.ld; void* yp = out.p; const int64_t ldy = out.ld;
     const float* g = w.g; const float* b = w.b; const int C = w.C; const float eps = w.eps; const int r = (int)rows;
-    push([=](hipStream_t s) { return launch_layernorm(d, xp, ldx, yp, ldy, g, b, r, C, eps, s); });
+    push([=](hipStream_t s) { return launch_layernorm(d, xp, ldx, yp, ldy, g, b, r, C, eps, s); }, "layernorm C=" + std::to_string(C));
   }
 
   void attention(const TView& q, const TView& k, const TView& v, const TView& o, const float* bias, int B, int heads, int Sq,
@@ -134,7 +141,9 @@ struct Builder {
     p.q = q.p; p.ldq = q.ld; p.k = k.p; p.ldk = k.ld; p.v = v.p; p.ldv = v.ld; p.o = o.p; p.ldo = o.ld;
     p.bias = bias; p.B = B; p.heads = heads; p.Sq = Sq; p.Skv = Skv; p.scale = 0.125f;
     const int d = dt;
-    push([p, d](hipStream_t s) { return launch_attention(d, p, s); });
+    push([p, d](hipStream_t s) { return launch_attention(d, p, s); },
+         "attention Sq=" + std::to_string(Sq) + " Skv=" + std::to_string(Skv) + " heads=" + std::to_string(heads),
+         4.0 * B * heads * (double)Sq * Skv * 64);
   }
 
   // ResnetBlock2D (resnet.py:549-597) / audioldm ResnetBlock (modules.py:155-175)
@@ -839,6 +848,37 @@ int Engine::denoise(const tango_denoise_args_t& a, hipStream_t s) {
   return 0;
 }
 
+int Program::run_profiled(hipStream_t s, std::string& report) const {
+  hipEvent_t a, b;
+  TANGO_HIP(hipEventCreate(&a));
+  TANGO_HIP(hipEventCreate(&b));
+  for (size_t i = 0; i < ops.size(); ++i) {
+    TANGO_HIP(hipEventRecord(a, s));
+    TANGO_TRY(ops[i](s));
+    TANGO_HIP(hipEventRecord(b, s));
+    TANGO_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    TANGO_HIP(hipEventElapsedTime(&ms, a, b));
+    char buf[64];
+    snprintf(buf, sizeof buf, "\t%.4f\t%.3f\n", ms, i < flops.size() ? flops[i] / 1e9 : 0.0);
+    report += (i < labels.size() ? labels[i] : std::string("op")) + buf;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return 0;
+}
+
+int Engine::profile_unet(int B2, int L, std::string& report, hipStream_t s) {
+  UNetPlan* P;
+  TANGO_TRY(get_unet_plan(B2, L, &P));
+  int64_t t = 500;
+  TANGO_TRY(ensure_temb(&t, 1, s));
+  TANGO_HIP(hipMemsetAsync(d_step, 0, 4, s));
+  TANGO_TRY(P->step.run(s));                 // warm-up (inputs are whatever the buffers hold)
+  TANGO_HIP(hipStreamSynchronize(s));
+  return P->step.run_profiled(s, report);
+}
+
 int Engine::last_denoise_ms(float* total_ms, float* per_step_ms) {
   if (last_steps <= 0) TANGO_FAIL("last_denoise_ms: no denoise call recorded");
   TANGO_HIP(hipEventSynchronize(ev1));
@@ -1164,6 +1204,17 @@ int tango_engine_vocode(tango_engine_t* h, const float* mel, int16_t* wav, int b
   return h->e->vocode(mel, wav, batch, mel_frames, n_samples, (hipStream_t)stream);
 }
 int tango_engine_vocoder_samples(tango_engine_t* h, int mel_frames) { return h->e->vocoder_samples(mel_frames); }
+
+int tango_engine_profile_unet(tango_engine_t* h, int batch2, int text_len, char* report, int report_cap, void* stream) {
+  std::string r;
+  int rc = h->e->profile_unet(batch2, text_len, r, (hipStream_t)stream);
+  if (report && report_cap > 0) {
+    const size_t n = std::min((size_t)report_cap - 1, r.size());
+    memcpy(report, r.data(), n);
+    report[n] = 0;
+  }
+  return rc;
+}
 
 int tango_engine_last_denoise_ms(tango_engine_t* h, float* total_ms, float* per_step_ms) {
   return h->e->last_denoise_ms(total_ms, per_step_ms);

@@ -213,6 +213,17 @@ class Engine:
             _lib.check(self.lib.tango_engine_denoise(self._h, C.byref(a), _stream_ptr()), "denoise")
         return latents
 
+    def profile_unet(self, batch2: int, text_len: int):
+        """per-op timing of one eager UNet step: list of (label, ms, gflop)"""
+        buf = C.create_string_buffer(1 << 20)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.tango_engine_profile_unet(self._h, batch2, text_len, buf, len(buf), _stream_ptr()), "profile_unet")
+        rows = []
+        for line in buf.value.decode().splitlines():
+            lab, ms, gf = line.rsplit("\t", 2)
+            rows.append((lab, float(ms), float(gf)))
+        return rows
+
     def last_denoise_ms(self):
         tot, per = C.c_float(), C.c_float()
         _lib.check(self.lib.tango_engine_last_denoise_ms(self._h, C.byref(tot), C.byref(per)), "last_denoise_ms")
