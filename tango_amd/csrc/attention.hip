@@ -9,6 +9,12 @@
 // In the 16x16 accumulator layout every lane owns ONE query column (q = lane & 15) and 4 kv rows per
 // 16-kv block, so the online-softmax state (m, l, rescale) is a per-lane scalar and row reductions are
 // in-register + two cross-group shuffles.  Softmax statistics and accumulation are fp32 always.
+//
+// V arrives already transposed ([B][heads][64][ldvt], written by the QKV / KV projection GEMM epilogue),
+// so both K and V^T tiles are plain 128-byte-row copies into XOR-swizzled LDS (conflict-free
+// ds_read_b128), two stages, ONE barrier per 64-key tile.  For 16-bit types the V^T tile columns are
+// stored in the order the P^T accumulator fragments present them ([4g..4g+3 | 16+4g..16+4g+3] adjacent),
+// so each PV fragment is a single ds_read_b128.
 #include "common.h"
 
 namespace tango {
@@ -35,19 +41,19 @@ template <> struct AMma<bf16> {
 };
 
 template <typename T, int QB>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   constexpr int EPV = 16 / (int)sizeof(T);
   constexpr int D = 64, KVT = 64;
-  constexpr int ROWB = D * (int)sizeof(T);      // bytes per K row (and per V^T row)
-  constexpr int LDSR = ROWB + 16;
-  constexpr int NKG = ROWB / 64;                // 64-byte k groups over head_dim
+  constexpr bool HALF = sizeof(T) == 2;
+  constexpr int ROWB = D * (int)sizeof(T);          // bytes per K row == bytes per V^T row (64 kv)
+  constexpr int LDSR = HALF ? ROWB : ROWB + 16;     // 128-byte rows are XOR-swizzled, 256-byte rows padded
+  constexpr int NKG = ROWB / 64;                    // 64-byte k groups over head_dim
   constexpr int PPR = ROWB / 16;
   constexpr int NPASS = KVT * PPR / 256;
-  constexpr bool HALF = sizeof(T) == 2;
+  constexpr int STAGE = 2 * KVT * LDSR;
+  constexpr float LOG2E = 1.4426950408889634f;
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KVT * LDSR];
-  unsigned char* Ks = smem;
-  unsigned char* Vt = smem + KVT * LDSR;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
@@ -56,9 +62,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 
   const T* Qp = (const T*)p.q + (int64_t)b * p.Sq * p.ldq + h * D;
   const T* Kp = (const T*)p.k + (int64_t)b * p.Skv * p.ldk + h * D;
-  const T* Vp = (const T*)p.v + (int64_t)b * p.Skv * p.ldv + h * D;
+  const T* Vp = (const T*)p.vt + ((int64_t)b * p.heads + h) * D * p.ldvt;    // [64][ldvt]
   T* Op = (T*)p.o + (int64_t)b * p.Sq * p.ldo + h * D;
   const float* bias = p.bias ? p.bias + (int64_t)b * p.Skv : nullptr;
+  const float sc2 = p.scale * LOG2E;
 
   u32x4 qf[QB][NKG];
 #pragma unroll
@@ -81,25 +88,54 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     for (int db = 0; db < 4; ++db) oacc[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  for (int kv0 = 0; kv0 < p.Skv; kv0 += KVT) {
-    // ---- stage K (row-major) and V (transposed) tiles ----
+  // ---- staging: thread -> (row, 16-byte piece) of the K tile and of the V^T tile ----
+  u32x4 kreg[NPASS], vreg[NPASS];
+  auto load_tile = [&](int kv0) {
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
       const int id = tid + i * 256;
       const int row = id / PPR, pc = id % PPR;
-      const int kv = kv0 + row;
-      u32x4 kvv = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
-      if (kv < p.Skv) {
-        kvv = *(const u32x4*)((const unsigned char*)(Kp + (int64_t)kv * p.ldk) + pc * 16);
-        vv = *(const u32x4*)((const unsigned char*)(Vp + (int64_t)kv * p.ldv) + pc * 16);
-      }
-      *(u32x4*)(Ks + row * LDSR + pc * 16) = kvv;
-      T e[EPV];
-      __builtin_memcpy(e, &vv, 16);
-#pragma unroll
-      for (int j = 0; j < EPV; ++j) *(T*)(Vt + (pc * EPV + j) * LDSR + row * (int)sizeof(T)) = e[j];
+      u32x4 kk = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
+      if (kv0 + row < p.Skv) kk = *(const u32x4*)((const unsigned char*)(Kp + (int64_t)(kv0 + row) * p.ldk) + pc * 16);
+      if (kv0 + pc * EPV < p.ldvt) vv = *(const u32x4*)((const unsigned char*)(Vp + (int64_t)row * p.ldvt + kv0) + pc * 16);
+      kreg[i] = kk; vreg[i] = vv;
     }
-    __syncthreads();
+  };
+  auto store_tile = [&](int st) {
+    unsigned char* Ks = smem + st * STAGE;
+    unsigned char* Vs = Ks + KVT * LDSR;
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      const int id = tid + i * 256;
+      const int row = id / PPR, pc = id % PPR;
+      if (HALF) {
+        *(u32x4*)(Ks + row * LDSR + ((pc ^ (row & 7)) * 16)) = kreg[i];
+        // V^T: piece pc holds kv = 8pc..8pc+7 of this 64-tile: 32-block j = pc>>2, c = (pc&3)*8 + e.
+        // column c = 16*hi + 4*gg + r is stored at c' = 8*gg + 4*hi + r (so [hi=0 | hi=1] of one gg are adjacent)
+        const int j = pc >> 2, hi = (pc >> 1) & 1, gg0 = (pc & 1) * 2;
+        const u32x2 lo = u32x2{vreg[i][0], vreg[i][1]}, hh = u32x2{vreg[i][2], vreg[i][3]};
+        // bytes within the row: 64*j + 2*(8*gg + 4*hi) ; 16-byte piece index = 4*j + gg, half = hi
+        unsigned char* vr = Vs + row * LDSR;
+        *(u32x2*)(vr + (((4 * j + gg0) ^ (row & 7)) * 16) + hi * 8) = lo;
+        *(u32x2*)(vr + (((4 * j + gg0 + 1) ^ (row & 7)) * 16) + hi * 8) = hh;
+      } else {
+        *(u32x4*)(Ks + row * LDSR + pc * 16) = kreg[i];
+        *(u32x4*)(Vs + row * LDSR + pc * 16) = vreg[i];
+      }
+    }
+  };
+
+  const int ntile = (p.Skv + KVT - 1) / KVT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntile; ++t) {
+    const int kv0 = t * KVT;
+    const bool more = t + 1 < ntile;
+    if (more) load_tile(kv0 + KVT);
+    const unsigned char* Ks = smem + (t & 1) * STAGE;
+    const unsigned char* Vs = Ks + KVT * LDSR;
 
     // ---- S^T = K Q^T ----
     f32x4 sacc[QB][4];
@@ -111,21 +147,25 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
       for (int ks = 0; ks < NKG; ++ks) {
-        const u32x4 kf = *(const u32x4*)(Ks + (kb * 16 + l15) * LDSR + ks * 64 + g * 16);
+        const int off = HALF ? (((ks * 4 + g) ^ (lane & 7)) * 16) : ks * 64 + g * 16;
+        const u32x4 kf = *(const u32x4*)(Ks + (kb * 16 + l15) * LDSR + off);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) AMma<T>::run(sacc[qb][kb], kf, qf[qb][ks]);
       }
     }
 
-    // ---- online softmax (per lane: one q column, 16 kv values) ----
+    // ---- online softmax in the exp2 domain (per lane: one q column, 16 kv values per q block) ----
     float bv[4][4];
+    const bool tail = (kv0 + KVT > p.Skv);
+    if (bias || tail) {
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+      for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kv = kv0 + kb * 16 + g * 4 + r;
-        bv[kb][r] = (kv < p.Skv) ? (bias ? bias[kv] : 0.f) : -1.0e30f;
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int kv = kv0 + kb * 16 + g * 4 + r;
+          bv[kb][r] = (kv < p.Skv) ? (bias ? bias[kv] * LOG2E : 0.f) : -1.0e30f;
+        }
+    }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       float mt = -1.0e30f;
@@ -133,20 +173,21 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float sv = sacc[qb][kb][r] * p.scale + bv[kb][r];
+          float sv = sacc[qb][kb][r] * sc2;
+          if (bias || tail) sv += bv[kb][r];
           sacc[qb][kb][r] = sv;
           mt = fmaxf(mt, sv);
         }
       mt = fmaxf(mt, __shfl_xor(mt, 16));
       mt = fmaxf(mt, __shfl_xor(mt, 32));
       const float mnew = fmaxf(mrow[qb], mt);
-      const float alpha = __expf(mrow[qb] - mnew);
+      const float alpha = __builtin_amdgcn_exp2f(mrow[qb] - mnew);
       float rs = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = __expf(sacc[qb][kb][r] - mnew);
+          const float pv = __builtin_amdgcn_exp2f(sacc[qb][kb][r] - mnew);
           sacc[qb][kb][r] = pv;
           rs += pv;
         }
@@ -170,12 +211,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
           for (int r = 0; r < 4; ++r) { e[r] = from_f<T>(sacc[qb][2 * j][r]); e[4 + r] = from_f<T>(sacc[qb][2 * j + 1][r]); }
           __builtin_memcpy(&pf[qb], e, 16);
         }
+        const int off = ((4 * j + g) ^ (lane & 7)) * 16;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-          const unsigned char* vr = Vt + (db * 16 + l15) * LDSR;
-          const u32x2 lo = *(const u32x2*)(vr + ((2 * j) * 16 + g * 4) * 2);
-          const u32x2 hi = *(const u32x2*)(vr + ((2 * j + 1) * 16 + g * 4) * 2);
-          const u32x4 vf = u32x4{lo[0], lo[1], hi[0], hi[1]};
+          const u32x4 vf = *(const u32x4*)(Vs + (db * 16 + l15) * LDSR + off);
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb) AMma<T>::run(oacc[qb][db], vf, pf[qb]);
         }
@@ -185,7 +224,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
       for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-          const u32x4 vf = *(const u32x4*)(Vt + (db * 16 + l15) * LDSR + (kb * 16 + g * 4) * 4);
+          const u32x4 vf = *(const u32x4*)(Vs + (db * 16 + l15) * LDSR + (kb * 16 + g * 4) * 4);
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb) {
             const u32x4 pf = __builtin_bit_cast(u32x4, sacc[qb][kb]);
@@ -194,6 +233,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         }
       }
     }
+    if (more) store_tile((t + 1) & 1);
     __syncthreads();
   }
 
@@ -215,12 +255,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 
 template <typename T>
 static int attn_launch(const AttnParams& p, hipStream_t s) {
-  if ((p.ldq * (int64_t)sizeof(T)) % 16 || (p.ldk * (int64_t)sizeof(T)) % 16 || (p.ldv * (int64_t)sizeof(T)) % 16 ||
+  if ((p.ldq * (int64_t)sizeof(T)) % 16 || (p.ldk * (int64_t)sizeof(T)) % 16 || (p.ldvt * (int64_t)sizeof(T)) % 16 ||
       (p.ldo * (int64_t)sizeof(T)) % 8)
     TANGO_FAIL("attention: ld alignment");
-  constexpr int QB = 2;
-  dim3 grid((unsigned)((p.Sq + 64 * QB - 1) / (64 * QB)), (unsigned)p.heads, (unsigned)p.B);
-  hipLaunchKernelGGL((attn_kernel<T, QB>), grid, dim3(256), 0, s, p);
+  if (p.Sq > 512) {
+    constexpr int QB = 2;
+    dim3 grid((unsigned)((p.Sq + 64 * QB - 1) / (64 * QB)), (unsigned)p.heads, (unsigned)p.B);
+    hipLaunchKernelGGL((attn_kernel<T, QB>), grid, dim3(256), 0, s, p);
+  } else {
+    constexpr int QB = 1;
+    dim3 grid((unsigned)((p.Sq + 64 * QB - 1) / (64 * QB)), (unsigned)p.heads, (unsigned)p.B);
+    hipLaunchKernelGGL((attn_kernel<T, QB>), grid, dim3(256), 0, s, p);
+  }
   TANGO_HIP(hipGetLastError());
   return 0;
 }

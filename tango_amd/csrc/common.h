@@ -82,7 +82,7 @@ struct View {
 // phase taps on channels-last [B, L, C].  K = taps * Cin, tap-major, Cin % BK == 0.
 // ------------------------------------------------------------------------------------------
 enum GatherMode : int { GATHER_1D = 0, GATHER_2D = 1 };
-enum Epi : int { EPI_NONE = 0, EPI_GEGLU = 1, EPI_I16 = 2 };
+enum Epi : int { EPI_NONE = 0, EPI_GEGLU = 1, EPI_I16 = 2, EPI_VT = 3 };
 
 struct GemmParams {
   const void* A = nullptr;   // T
@@ -113,6 +113,11 @@ struct GemmParams {
   float alpha = 1.f;
   float out_scale = 1.f;     // applied last (EPI_I16: 32768)
   int bias_rows = 0;         // bias indexed by output row instead of column
+  // EPI_VT: columns n >= vt_n0 are the V projection and are stored TRANSPOSED for the attention kernel:
+  //   vt[((m / vt_S) * (N - vt_n0) + (n - vt_n0)) * vt_ld + (m % vt_S)]   ( == [B][heads][64][vt_ld] )
+  void* vt = nullptr;
+  int vt_n0 = 0, vt_S = 1;
+  int64_t vt_ld = 0;
   // batched GEMM (blockIdx.z)
   int batch = 1;
   int64_t sA = 0, sW = 0, sO = 0, sR = 0, sBias = 0;
@@ -141,7 +146,7 @@ int launch_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy
 struct AttnParams {
   const void* q; int64_t ldq;     // [B*Sq, >= heads*64]
   const void* k; int64_t ldk;     // [B*Skv, ...]
-  const void* v; int64_t ldv;
+  const void* vt; int64_t ldvt;   // V transposed: [B][heads][64][ldvt] (columns >= Skv must be zero / finite)
   void* o; int64_t ldo;
   const float* bias;              // [B][Skv] additive or null
   int B, heads, Sq, Skv;

@@ -31,6 +31,10 @@ struct GOpt {
   int epi = EPI_NONE;
   bool out_f32 = false;
   bool use_bias = true;
+  // EPI_VT (fused QKV / KV projections): columns >= vt_n0 go transposed into `vt` [B][C][vt_ld]
+  void* vt = nullptr;
+  int vt_n0 = 0, vt_S = 1;
+  int64_t vt_ld = 0;
 };
 
 struct Builder {
@@ -83,6 +87,7 @@ struct Builder {
     if (o.residual) { p.R = o.residual->p; p.ldr = o.residual->ld; }
     p.a_act = o.a_act; p.a_slope = o.a_slope; p.e_act = o.e_act; p.e_slope = o.e_slope; p.epi = o.epi;
     p.bias2 = o.bias2; p.bias2_stride = o.bias2_stride; p.step_ptr = o.bias2 ? E.d_step : nullptr;
+    if (o.vt) { p.epi = EPI_VT; p.vt = o.vt; p.vt_n0 = o.vt_n0; p.vt_S = o.vt_S; p.vt_ld = o.vt_ld; }
     gemm(p, "linear");
   }
 
@@ -135,10 +140,10 @@ struct Builder {
     push([=](hipStream_t s) { return launch_layernorm(d, xp, ldx, yp, ldy, g, b, r, C, eps, s); }, "layernorm C=" + std::to_string(C));
   }
 
-  void attention(const TView& q, const TView& k, const TView& v, const TView& o, const float* bias, int B, int heads, int Sq,
-                 int Skv) {
+  void attention(const TView& q, const TView& k, const void* vt, int64_t ldvt, const TView& o, const float* bias, int B, int heads,
+                 int Sq, int Skv) {
     AttnParams p;
-    p.q = q.p; p.ldq = q.ld; p.k = k.p; p.ldk = k.ld; p.v = v.p; p.ldv = v.ld; p.o = o.p; p.ldo = o.ld;
+    p.q = q.p; p.ldq = q.ld; p.k = k.p; p.ldk = k.ld; p.vt = vt; p.ldvt = ldvt; p.o = o.p; p.ldo = o.ld;
     p.bias = bias; p.B = B; p.heads = heads; p.Sq = Sq; p.Skv = Skv; p.scale = 0.125f;
     const int d = dt;
     push([p, d](hipStream_t s) { return launch_attention(d, p, s); },
@@ -170,8 +175,8 @@ struct Builder {
   }
 
   // Transformer2DModel (transformer_2d.py:214-321) + BasicTransformerBlock (attention.py:276-335)
-  void transformer(const XfW& w, const TView& x, int B, int H, int W, int groups, const TView& kv, const float* bias, int L,
-                   const TView& out) {
+  void transformer(const XfW& w, const TView& x, int B, int H, int W, int groups, const TView& kv, const void* kvt,
+                   const float* bias, int L, const TView& out) {
     const int C = w.C, HW = H * W;
     const int64_t rows = (int64_t)B * HW;
     const size_t m = A.mark();
@@ -181,17 +186,18 @@ struct Builder {
     linear(t0, rows, w.proj_in, h);
     TView t1 = alloc(rows, C);
     layernorm(h, rows, w.ln1, t1);
-    TView qkv = alloc(rows, 3 * C);
+    TView qkv = alloc(rows, 2 * C);                 // [q | k]; v goes transposed into vt [B][C][HW]
+    void* vt = A.alloc((size_t)rows * C * esz);
     GOpt nb; nb.use_bias = false;
-    linear(t1, rows, w.qkv, qkv, nb);
+    { GOpt o = nb; o.vt = vt; o.vt_n0 = 2 * C; o.vt_S = HW; o.vt_ld = HW; linear(t1, rows, w.qkv, qkv, o); }
     TView a = alloc(rows, C);
-    attention(slice(qkv, 0, C, esz), slice(qkv, C, C, esz), slice(qkv, 2 * C, C, esz), a, nullptr, B, w.heads, HW, HW);
+    attention(slice(qkv, 0, C, esz), slice(qkv, C, C, esz), vt, HW, a, nullptr, B, w.heads, HW, HW);
     TView h1 = alloc(rows, C);
     { GOpt o; o.residual = &h; linear(a, rows, w.o1, h1, o); }
     layernorm(h1, rows, w.ln2, t1);
     TView q = slice(qkv, 0, C, esz);   // reuse the qkv buffer for the cross-attention query
     linear(t1, rows, w.q2, q, nb);
-    attention(q, slice(kv, 0, C, esz), slice(kv, C, C, esz), a, bias, B, w.heads, HW, L);
+    attention(q, kv, kvt, (L + 7) / 8 * 8, a, bias, B, w.heads, HW, L);
     TView h2 = h;                       // h is dead after h1 was produced
     { GOpt o; o.residual = &h1; linear(a, rows, w.o2, h2, o); }
     layernorm(h2, rows, w.ln3, t1);
@@ -646,18 +652,22 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
   P.bias = (float*)A.alloc((size_t)B2 * L * 4);
 
   // cross-attention K/V for every transformer: step-invariant, computed by P.pre once per call
-  std::vector<TView> kvs(all_xf.size());
+  std::vector<TView> kvs(all_xf.size());       // K  [B2*L][C]
+  std::vector<void*> kvts(all_xf.size());      // V^T [B2][C][Lp], Lp = L rounded up to 8 (pad columns stay zero)
+  const int Lp = (L + 7) / 8 * 8;
   {
     Builder pb{*this, A, &P.pre, record, dt, esz};
     for (size_t i = 0; i < all_xf.size(); ++i) {
-      kvs[i] = pb.alloc((int64_t)B2 * L, 2 * all_xf[i]->C);
-      GOpt nb; nb.use_bias = false;
-      pb.linear(enc, (int64_t)B2 * L, all_xf[i]->kv2, kvs[i], nb);
+      const int C = all_xf[i]->C;
+      kvs[i] = pb.alloc((int64_t)B2 * L, C);
+      kvts[i] = A.alloc((size_t)B2 * C * Lp * esz);
+      GOpt o; o.use_bias = false; o.vt = kvts[i]; o.vt_n0 = C; o.vt_S = L; o.vt_ld = Lp;
+      pb.linear(enc, (int64_t)B2 * L, all_xf[i]->kv2, kvs[i], o);
     }
   }
-  auto kv_of = [&](const XfW* w) -> const TView& {
-    for (size_t i = 0; i < all_xf.size(); ++i) if (all_xf[i] == w) return kvs[i];
-    return kvs[0];
+  auto kv_idx = [&](const XfW* w) -> size_t {
+    for (size_t i = 0; i < all_xf.size(); ++i) if (all_xf[i] == w) return i;
+    return 0;
   };
 
   // concat buffers of the up path: up resnet u = i*(lpb+1)+j consumes skip number (nskip-1-u)
@@ -696,7 +706,7 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
         TView r = b.alloc(rows_at(i), ch[i]);
         b.resblock(down[i].res[j], h, B2, HH(i), WW(i), G, r);
         TView o = skip_dst();
-        b.transformer(down[i].xf[j], r, B2, HH(i), WW(i), G, kv_of(&down[i].xf[j]), P.bias, L, o);
+        b.transformer(down[i].xf[j], r, B2, HH(i), WW(i), G, kvs[kv_idx(&down[i].xf[j])], kvts[kv_idx(&down[i].xf[j])], P.bias, L, o);
         h = o;
       } else {
         TView o = skip_dst();
@@ -716,7 +726,7 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
     TView r0 = b.alloc(rows_at(lvl), ch[lvl]);
     b.resblock(mid_res0, h, B2, HH(lvl), WW(lvl), G, r0);
     TView x1 = b.alloc(rows_at(lvl), ch[lvl]);
-    b.transformer(mid_xf, r0, B2, HH(lvl), WW(lvl), G, kv_of(&mid_xf), P.bias, L, x1);
+    b.transformer(mid_xf, r0, B2, HH(lvl), WW(lvl), G, kvs[kv_idx(&mid_xf)], kvts[kv_idx(&mid_xf)], P.bias, L, x1);
     TView dst = Builder::slice(cats[0].buf, 0, cats[0].c1, esz);
     b.resblock(mid_res1, x1, B2, HH(lvl), WW(lvl), G, dst);
   }
@@ -737,7 +747,7 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
       if (xa) {
         TView r = b.alloc(rows_at(lvl), outc);
         b.resblock(up[i].res[j], c.buf, B2, HH(lvl), WW(lvl), G, r);
-        b.transformer(up[i].xf[j], r, B2, HH(lvl), WW(lvl), G, kv_of(&up[i].xf[j]), P.bias, L, dst);
+        b.transformer(up[i].xf[j], r, B2, HH(lvl), WW(lvl), G, kvs[kv_idx(&up[i].xf[j])], kvts[kv_idx(&up[i].xf[j])], P.bias, L, dst);
       } else {
         b.resblock(up[i].res[j], c.buf, B2, HH(lvl), WW(lvl), G, dst);
       }
@@ -770,8 +780,9 @@ int Engine::get_unet_plan(int B2, int L, UNetPlan** out) {
   Arena m;
   TANGO_TRY(build_unet(*P, m, false));
   TANGO_HIP(hipMalloc((void**)&P->slab, m.peak + 256));
+  TANGO_HIP(hipMemset(P->slab, 0, m.peak + 256));   // V^T pad columns (L not a multiple of 8) must stay zero
   Arena a; a.base = P->slab;
-  P->pre.ops.clear(); P->step.ops.clear();
+  P->pre.ops.clear(); P->step.ops.clear(); P->pre.labels.clear(); P->step.labels.clear(); P->pre.flops.clear(); P->step.flops.clear();
   TANGO_TRY(build_unet(*P, a, true));
   *out = P.get();
   unet_plans[key] = std::move(P);

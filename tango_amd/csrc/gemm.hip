@@ -7,6 +7,10 @@
 // feeds one v_mfma_f32_16x16x32_{f16,bf16} or four v_mfma_f32_16x16x4_f32 (k order inside a group
 // is a fixed permutation shared by both operands, which leaves the dot product unchanged).
 //
+// v2 structure (round 1): 128-byte tile rows, XOR-swizzled 16-byte pieces (piece ^ (row & 7)) so every
+// ds_read_b128 lane group hits 16 distinct slots; two LDS stages, ONE barrier per k-chunk: chunk k+1
+// is fetched HBM->VGPR while chunk k is multiplied, then written to the other stage.
+//
 // Reference ops this kernel replaces (ATen dispatches): convolution (66/UNet step),
 // mm/addmm (216), and the VAE / HiFi-GAN convolution + conv_transpose1d calls.
 #include "common.h"
@@ -44,8 +48,10 @@ template <typename T> __device__ __forceinline__ u32x4 act_vec(u32x4 v, int act,
   return v;
 }
 
-template <typename T, int BM, int BN, int BKB, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+enum : int { MODE_LINEAR = 0, MODE_CONV2D = 1, MODE_CONV1D = 2 };
+
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   constexpr int EPV = 16 / (int)sizeof(T);     // elements per 16-byte vector
   constexpr int BK = BKB / (int)sizeof(T);     // k elements per chunk
   constexpr int NKG = BKB / 64;                // 64-byte k groups per chunk
@@ -53,15 +59,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   constexpr int RPP = 256 / PPR;               // tile rows staged per pass
   constexpr int AP = (BM + RPP - 1) / RPP;
   constexpr int BP = (BN + RPP - 1) / RPP;
-  constexpr int LDSR = BKB + 16;               // padded LDS row (bytes)
+  constexpr bool SWZ = (BKB == 128);           // XOR swizzle for 128-byte rows, +16 B padding otherwise
+  constexpr int LDSR = SWZ ? 128 : BKB + 16;
+  constexpr int STAGE = (BM + BN) * LDSR;
   constexpr int WMR = BM / WM, WNR = BN / WN;
   constexpr int TM = WMR / 16, TN = WNR / 16;
   static_assert(WM * WN == 4, "4 waves");
   static_assert(WMR % 16 == 0 && WNR % 16 == 0, "tile");
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * LDSR];
-  unsigned char* Xs = smem;
-  unsigned char* Ws = smem + BM * LDSR;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
   const int MT = (p.M + BM - 1) / BM, NT = (p.N + BN - 1) / BN;
   int bid = blockIdx.x;
@@ -80,28 +86,40 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
   const int prow = tid / PPR, pcol = tid % PPR;
+  // staging position of this thread's 16-byte piece inside a tile row (row & 7 == prow & 7: RPP % 8 == 0)
+  const int spos = SWZ ? ((pcol ^ (prow & 7)) * 16) : pcol * 16;
 
-  // per-thread gather rows
-  int a_rowb[AP], a_c0[AP], a_c1[AP];
+  // ---- per-thread gather rows ----
+  int64_t a_base[AP];          // LINEAR: byte offset of the row; conv: batch base ROW index (or -1)
+  int a_c0[AP], a_c1[AP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
     const int rl = i * RPP + prow;
     const int m = m0 + rl;
-    a_rowb[i] = -1; a_c0[i] = 0; a_c1[i] = 0;
+    a_base[i] = -1; a_c0[i] = 0; a_c1[i] = 0;
     if (rl < BM && m < p.M) {
-      if (p.mode == GATHER_2D) {
+      if (MODE == MODE_LINEAR) {
+        a_base[i] = ((int64_t)m * p.lda + pcol * EPV) * (int64_t)sizeof(T);
+      } else if (MODE == MODE_CONV2D) {
         const int hw = p.H * p.Wd;
         const int b = m / hw, rem = m - b * hw;
         const int y = rem / p.Wd, x = rem - y * p.Wd;
-        a_rowb[i] = b * p.Hin * p.Win;
+        a_base[i] = (int64_t)b * p.Hin * p.Win;
         a_c0[i] = y * p.stride - 1;
         a_c1[i] = x * p.stride - 1;
       } else {
         const int b = m / p.rows_pb, q = m - b * p.rows_pb;
-        a_rowb[i] = b * p.Lin;
+        a_base[i] = (int64_t)b * p.Lin;
         a_c0[i] = q * p.in_mul + p.in_off;
       }
     }
+  }
+  const unsigned char* w_ptr[BP];
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    const int rl = i * RPP + prow;
+    const int n = n0 + rl;
+    w_ptr[i] = (rl < BN && n < p.N) ? Wb + ((int64_t)n * p.Kp + pcol * EPV) * (int64_t)sizeof(T) : nullptr;
   }
 
   f32x4 acc[TN][TM];
@@ -115,68 +133,89 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 
   auto load_chunk = [&](int kc) {
     const int k0 = kc * BK;
-    const int tap = k0 / p.Cin;
-    const int cc = k0 - tap * p.Cin;
-    int dy = 0, dx = 0;
-    if (p.mode == GATHER_2D) { dy = tap / 3; dx = tap - dy * 3; }
+    int tap = 0, cc = k0, dy = 0, dx = 0;
+    if (MODE != MODE_LINEAR) {
+      tap = k0 / p.Cin;
+      cc = k0 - tap * p.Cin;
+      if (MODE == MODE_CONV2D) { dy = tap / 3; dx = tap - dy * 3; }
+    }
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (a_rowb[i] >= 0) {
-        int64_t srow; bool ok;
-        if (p.mode == GATHER_2D) {
-          const int iy = a_c0[i] + dy, ix = a_c1[i] + dx;
-          ok = (unsigned)iy < (unsigned)(p.Hin << p.ups) && (unsigned)ix < (unsigned)(p.Win << p.ups);
-          srow = (int64_t)a_rowb[i] + (int64_t)(iy >> p.ups) * p.Win + (ix >> p.ups);
-        } else {
-          const int idx = a_c0[i] + tap * p.tap_step;
-          ok = (unsigned)idx < (unsigned)p.Lin;
-          srow = (int64_t)a_rowb[i] + idx;
-        }
-        if (ok) {
-          v = *(const u32x4*)(Ab + (srow * p.lda + cc + pcol * EPV) * (int64_t)sizeof(T));
+      if (a_base[i] >= 0) {
+        if (MODE == MODE_LINEAR) {
+          v = *(const u32x4*)(Ab + a_base[i] + (int64_t)k0 * (int64_t)sizeof(T));
           if (p.a_act != ACT_NONE) v = act_vec<T>(v, p.a_act, p.a_slope);
+        } else {
+          int64_t srow; bool ok;
+          if (MODE == MODE_CONV2D) {
+            const int iy = a_c0[i] + dy, ix = a_c1[i] + dx;
+            ok = (unsigned)iy < (unsigned)(p.Hin << p.ups) && (unsigned)ix < (unsigned)(p.Win << p.ups);
+            srow = a_base[i] + (int64_t)(iy >> p.ups) * p.Win + (ix >> p.ups);
+          } else {
+            const int idx = a_c0[i] + tap * p.tap_step;
+            ok = (unsigned)idx < (unsigned)p.Lin;
+            srow = a_base[i] + idx;
+          }
+          if (ok) {
+            v = *(const u32x4*)(Ab + (srow * p.lda + cc + pcol * EPV) * (int64_t)sizeof(T));
+            if (p.a_act != ACT_NONE) v = act_vec<T>(v, p.a_act, p.a_slope);
+          }
         }
       }
       ar[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
-      const int rl = i * RPP + prow;
-      const int n = n0 + rl;
       u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (rl < BN && n < p.N) v = *(const u32x4*)(Wb + ((int64_t)n * p.Kp + k0 + pcol * EPV) * (int64_t)sizeof(T));
+      if (w_ptr[i]) v = *(const u32x4*)(w_ptr[i] + (int64_t)k0 * (int64_t)sizeof(T));
       br[i] = v;
     }
   };
-
-  load_chunk(0);
-  for (int kc = 0; kc < nk; ++kc) {
+  auto store_stage = [&](int st) {
+    unsigned char* Xs = smem + st * STAGE;
+    unsigned char* Ws = Xs + BM * LDSR;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       const int rl = i * RPP + prow;
-      if (rl < BM) *(u32x4*)(Xs + rl * LDSR + pcol * 16) = ar[i];
+      if (rl < BM) *(u32x4*)(Xs + rl * LDSR + spos) = ar[i];
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
       const int rl = i * RPP + prow;
-      if (rl < BN) *(u32x4*)(Ws + rl * LDSR + pcol * 16) = br[i];
+      if (rl < BN) *(u32x4*)(Ws + rl * LDSR + spos) = br[i];
     }
-    __syncthreads();
-    if (kc + 1 < nk) load_chunk(kc + 1);
+  };
+
+  // fragment read offsets inside a row: (row & 7) == (lane & 7) because tile bases are multiples of 16
+  int koff[NKG];
+#pragma unroll
+  for (int ks = 0; ks < NKG; ++ks)
+    koff[ks] = SWZ ? (((ks * 4 + (lane >> 4)) ^ (lane & 7)) * 16) : ks * 64 + (lane >> 4) * 16;
+  const int xrow = (wm * WMR + (lane & 15)) * LDSR;
+  const int wrow = (wn * WNR + (lane & 15)) * LDSR;
+
+  load_chunk(0);
+  store_stage(0);
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    const bool more = kc + 1 < nk;
+    if (more) load_chunk(kc + 1);
+    const unsigned char* Xs = smem + (kc & 1) * STAGE;
+    const unsigned char* Ws = Xs + BM * LDSR;
 #pragma unroll
     for (int ks = 0; ks < NKG; ++ks) {
       u32x4 wf[TN], xf[TM];
-      const int koff = ks * 64 + (lane >> 4) * 16;
 #pragma unroll
-      for (int a = 0; a < TN; ++a) wf[a] = *(const u32x4*)(Ws + (wn * WNR + a * 16 + (lane & 15)) * LDSR + koff);
+      for (int a = 0; a < TN; ++a) wf[a] = *(const u32x4*)(Ws + wrow + a * 16 * LDSR + koff[ks]);
 #pragma unroll
-      for (int b = 0; b < TM; ++b) xf[b] = *(const u32x4*)(Xs + (wm * WMR + b * 16 + (lane & 15)) * LDSR + koff);
+      for (int b = 0; b < TM; ++b) xf[b] = *(const u32x4*)(Xs + xrow + b * 16 * LDSR + koff[ks]);
 #pragma unroll
       for (int a = 0; a < TN; ++a)
 #pragma unroll
         for (int b = 0; b < TM; ++b) Mma<T>::run(acc[a][b], wf[a], xf[b]);
     }
+    if (more) store_stage((kc + 1) & 1);
     __syncthreads();
   }
 
@@ -191,51 +230,68 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   Ob += (int64_t)blockIdx.z * p.sO * osz;
   if (Rb) Rb += (int64_t)blockIdx.z * p.sR * (int64_t)sizeof(T);
 
+  int64_t orow[TM], vtrow[TM];
 #pragma unroll
   for (int b = 0; b < TM; ++b) {
     const int m = m0 + wm * WMR + b * 16 + (lane & 15);
-    if (m >= p.M) continue;
-    int64_t orow = m;
-    if (p.mode == GATHER_1D) {
-      const int bb = m / p.rows_pb, q = m - bb * p.rows_pb;
-      orow = (int64_t)bb * p.Lout + (int64_t)q * p.out_mul + p.out_off;
+    orow[b] = -1; vtrow[b] = 0;
+    if (m < p.M) {
+      if (p.epi == EPI_VT) {
+        const int bb = m / p.vt_S;
+        vtrow[b] = (int64_t)bb * (p.N - p.vt_n0) * p.vt_ld + (m - bb * p.vt_S);
+      }
+      if (MODE == MODE_CONV1D) {
+        const int bb = m / p.rows_pb, q = m - bb * p.rows_pb;
+        orow[b] = (int64_t)bb * p.Lout + (int64_t)q * p.out_mul + p.out_off;
+      } else {
+        orow[b] = m;
+      }
     }
-    const float rbias = (bias && p.bias_rows) ? bias[orow] : 0.f;
+  }
+
 #pragma unroll
-    for (int a = 0; a < TN; ++a) {
-      if (p.epi == EPI_GEGLU && (a & 1)) continue;
-      const int nt = n0 + wn * WNR + a * 16;   // tile base column (packed order)
-      const int n = nt + g4;
-      if (n >= p.N) continue;
-      float v[4];
+  for (int a = 0; a < TN; ++a) {
+    if (p.epi == EPI_GEGLU && (a & 1)) continue;
+    const int nt = n0 + wn * WNR + a * 16;   // tile base column (packed order)
+    const int n = nt + g4;
+    if (n >= p.N) continue;
+    // per-column constants of this lane's 4 output channels
+    float cb[4] = {0.f, 0.f, 0.f, 0.f}, cg[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!p.bias_rows) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float x = acc[a][b][r] * p.alpha;
         if (n + r < p.N) {
-          if (bias) x += p.bias_rows ? rbias : bias[n + r];
-          if (bias2) x += bias2[n + r];
+          if (bias) cb[r] = bias[n + r];
+          if (bias2) cb[r] += bias2[n + r];
+          if (p.epi == EPI_GEGLU && bias) cg[r] = bias[n + 16 + r];
         }
-        v[r] = x;
       }
-      int oc = n;
-      int ncols = p.N;
+    }
+    int oc = n, ncols = p.N;
+    if (p.epi == EPI_GEGLU) { oc = (nt >> 1) + g4; ncols = p.N >> 1; }
+    const bool to_vt = (p.epi == EPI_VT) && n >= p.vt_n0;
+    if (p.epi == EPI_VT) ncols = p.vt_n0;
+    const bool full = (oc + 3 < ncols);
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      if (orow[b] < 0) continue;
+      float v[4];
+      const float rb = (bias && p.bias_rows) ? bias[orow[b]] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha + cb[r] + rb;
       if (p.epi == EPI_GEGLU) {
         // packed rows: [16 value | 16 gate] blocks -> out col = nt/2 + g4 + r
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float gt = acc[a + 1 < TN ? a + 1 : a][b][r] * p.alpha;
-          if (bias) gt += bias[n + 16 + r];
+          const float gt = acc[a + 1 < TN ? a + 1 : a][b][r] * p.alpha + cg[r];
           v[r] = v[r] * gelu_erf_f(gt);
         }
-        oc = (nt >> 1) + g4;
-        ncols = p.N >> 1;
       } else if (p.e_act != ACT_NONE) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.e_act, p.e_slope);
       }
-      const bool full = (oc + 3 < ncols);
       if (Rb) {
-        const T* rp = (const T*)Rb + orow * p.ldr + oc;
+        const T* rp = (const T*)Rb + orow[b] * p.ldr + oc;
         if (full && ((p.ldr | oc) & 3) == 0) {
           T rv[4];
           __builtin_memcpy(rv, rp, 4 * sizeof(T));
@@ -250,12 +306,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= p.out_scale;
       }
-      if (p.epi == EPI_I16) {
-        int16_t* op = (int16_t*)Ob + orow * p.ldo + oc;
+      if (to_vt) {
+        T* vp = (T*)p.vt + vtrow[b] + (int64_t)(n - p.vt_n0) * p.vt_ld;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n + r < p.N) vp[(int64_t)r * p.vt_ld] = from_f<T>(v[r]);
+      } else if (p.epi == EPI_I16) {
+        int16_t* op = (int16_t*)Ob + orow[b] * p.ldo + oc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (oc + r < ncols) op[r] = (int16_t)(int)v[r];   // C truncation, int16 wrap (hifigan/utilities.py:81)
       } else if (p.out_f32) {
-        float* op = (float*)Ob + orow * p.ldo + oc;
+        float* op = (float*)Ob + orow[b] * p.ldo + oc;
         if (full && ((p.ldo | oc) & 3) == 0) {
           *(f32x4*)op = f32x4{v[0], v[1], v[2], v[3]};
         } else {
@@ -263,7 +323,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
           for (int r = 0; r < 4; ++r) if (oc + r < ncols) op[r] = v[r];
         }
       } else {
-        T* op = (T*)Ob + orow * p.ldo + oc;
+        T* op = (T*)Ob + orow[b] * p.ldo + oc;
         T tv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) tv[r] = from_f<T>(v[r]);
@@ -278,26 +338,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 }
 
-template <typename T, int BM, int BN, int BKB, int WM, int WN>
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int MODE>
 static int launch_cfg(const GemmParams& p, hipStream_t s) {
   const int MT = (p.M + BM - 1) / BM, NT = (p.N + BN - 1) / BN;
   dim3 grid((unsigned)(MT * NT), 1, (unsigned)p.batch);
-  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, BKB, WM, WN>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, BKB, WM, WN, MODE>), grid, dim3(256), 0, s, p);
   TANGO_HIP(hipGetLastError());
   return 0;
 }
 
-template <typename T, int BKB>
+template <typename T, int BKB, int MODE>
 static int launch_tile(const GemmParams& p, hipStream_t s) {
   if (p.epi == EPI_GEGLU) {
     if (p.N % 32 != 0) TANGO_FAIL("GEGLU gemm needs N % 32 == 0");
-    return launch_cfg<T, 128, 128, BKB, 2, 2>(p, s);
+    return launch_cfg<T, 128, 128, BKB, 2, 2, MODE>(p, s);
   }
-  if (p.N % 160 == 0) return launch_cfg<T, 128, 160, BKB, 2, 2>(p, s);
-  if (p.N >= 96) return launch_cfg<T, 128, 128, BKB, 2, 2>(p, s);
-  if (p.N > 32) return launch_cfg<T, 128, 64, BKB, 2, 2>(p, s);
-  if (p.N > 16) return launch_cfg<T, 256, 32, BKB, 4, 1>(p, s);
-  return launch_cfg<T, 256, 16, BKB, 4, 1>(p, s);
+  if (p.N % 160 == 0) return launch_cfg<T, 128, 160, BKB, 2, 2, MODE>(p, s);
+  if (p.N >= 96) return launch_cfg<T, 128, 128, BKB, 2, 2, MODE>(p, s);
+  if (p.N > 32) return launch_cfg<T, 128, 64, BKB, 2, 2, MODE>(p, s);
+  if (p.N > 16) return launch_cfg<T, 256, 32, BKB, 4, 1, MODE>(p, s);
+  return launch_cfg<T, 256, 16, BKB, 4, 1, MODE>(p, s);
+}
+
+template <typename T, int BKB>
+static int launch_mode(const GemmParams& p, hipStream_t s) {
+  if (p.mode == GATHER_2D) return launch_tile<T, BKB, MODE_CONV2D>(p, s);
+  const bool linear = p.taps == 1 && p.rows_pb == p.M && p.in_mul == 1 && p.in_off == 0 && p.out_mul == 1 && p.out_off == 0 &&
+                      p.Lin >= p.M;
+  if (linear) return launch_tile<T, BKB, MODE_LINEAR>(p, s);
+  return launch_tile<T, BKB, MODE_CONV1D>(p, s);
 }
 
 template <typename T>
@@ -306,8 +375,8 @@ static int launch_t(const GemmParams& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return 0;
   if (p.K % p.Cin != 0) TANGO_FAIL("gemm: K must be taps*Cin");
   if ((p.lda * (int64_t)sizeof(T)) % 16 != 0 || (p.Kp * (int64_t)sizeof(T)) % 16 != 0) TANGO_FAIL("gemm: lda/Kp must be 16-byte multiples");
-  if (cb % 128 == 0) return launch_tile<T, 128>(p, s);
-  if (cb % 64 == 0) return launch_tile<T, 64>(p, s);
+  if (cb % 128 == 0) return launch_mode<T, 128>(p, s);
+  if (cb % 64 == 0) return launch_mode<T, 64>(p, s);
   TANGO_FAIL("gemm: Cin*sizeof(T) must be a multiple of 64 bytes");
 }
 

@@ -38,6 +38,28 @@ static int to_f32(int dt, const void* src, int64_t ld, float* dst, int64_t rows,
   return 0;
 }
 
+// v [B][S][C] -> vt [B][C][ldvt] (what the fused projection epilogue produces in the engine)
+template <typename T>
+__global__ void transpose_v_kernel(const T* __restrict__ v, T* __restrict__ vt, int B, int S, int C, int64_t ldvt) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * S * C) return;
+  const int c = (int)(i % C);
+  const int64_t bs = i / C;
+  const int s = (int)(bs % S), b = (int)(bs / S);
+  vt[((int64_t)b * C + c) * ldvt + s] = v[i];
+}
+static int transpose_v(int dt, const void* v, void* vt, int B, int S, int C, int64_t ldvt, hipStream_t s) {
+  const unsigned nb = (unsigned)(((int64_t)B * S * C + 255) / 256);
+  switch (dt) {
+    case DT_F32: hipLaunchKernelGGL((transpose_v_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)v, (float*)vt, B, S, C, ldvt); break;
+    case DT_F16: hipLaunchKernelGGL((transpose_v_kernel<f16>), dim3(nb), dim3(256), 0, s, (const f16*)v, (f16*)vt, B, S, C, ldvt); break;
+    case DT_BF16: hipLaunchKernelGGL((transpose_v_kernel<bf16>), dim3(nb), dim3(256), 0, s, (const bf16*)v, (bf16*)vt, B, S, C, ldvt); break;
+    default: TANGO_FAIL("transpose_v: bad dtype");
+  }
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
 // [B, C, L] fp32 <-> channels-last T [B*L, C] are the NCHW<->NHWC kernels with HW = L
 }  // namespace tango
 
@@ -215,12 +237,16 @@ int tango_op_attention(int dt, const float* q, const float* k, const float* v, c
   void* kt = sc.get((size_t)B * Skv * C * esz);
   void* vt = sc.get((size_t)B * Skv * C * esz);
   void* ot = sc.get((size_t)B * Sq * C * esz);
-  if (!qt || !kt || !vt || !ot) TANGO_FAIL("op_attention: alloc");
+  const int64_t ldvt = (Skv + 7) / 8 * 8;
+  void* vtt = sc.get((size_t)B * C * ldvt * esz);
+  if (!qt || !kt || !vt || !ot || !vtt) TANGO_FAIL("op_attention: alloc");
+  TANGO_HIP(hipMemsetAsync(vtt, 0, (size_t)B * C * ldvt * esz, s));
   TANGO_TRY(launch_cast_rows(dt, q, qt, C, B * Sq, C, s));
   TANGO_TRY(launch_cast_rows(dt, k, kt, C, B * Skv, C, s));
   TANGO_TRY(launch_cast_rows(dt, v, vt, C, B * Skv, C, s));
+  TANGO_TRY(transpose_v(dt, vt, vtt, B, Skv, C, ldvt, s));
   AttnParams p;
-  p.q = qt; p.ldq = C; p.k = kt; p.ldk = C; p.v = vt; p.ldv = C; p.o = ot; p.ldo = C; p.bias = bias;
+  p.q = qt; p.ldq = C; p.k = kt; p.ldk = C; p.vt = vtt; p.ldvt = ldvt; p.o = ot; p.ldo = C; p.bias = bias;
   p.B = B; p.heads = heads; p.Sq = Sq; p.Skv = Skv; p.scale = scale;
   TANGO_TRY(launch_attention(dt, p, s));
   TANGO_TRY(to_f32(dt, ot, C, out, (int64_t)B * Sq, C, s));
