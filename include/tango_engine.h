@@ -144,6 +144,8 @@ int tango_op_conv2d(int dtype, const float* x, const float* w, const float* bias
                     int Cout, int stride, int upsample, void* stream);
 int tango_op_linear(int dtype, const float* x, const float* w, const float* bias, const float* residual, float* out, int M,
                     int N, int K, int a_act, int e_act, int geglu, void* stream);
+int tango_op_linear_ln(int dtype, const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                       const float* residual, float* out, int M, int N, int K, int geglu, float eps, void* stream);
 int tango_op_conv1d(int dtype, const float* x, const float* w, const float* bias, const float* residual, float* out, int B,
                     int Cin, int L, int Cout, int k, int dilation, int a_act, float a_slope, int e_act, float e_slope, void* stream);
 int tango_op_conv_transpose1d(int dtype, const float* x, const float* w, const float* bias, float* out, int B, int Cin, int L,

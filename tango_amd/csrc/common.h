@@ -118,12 +118,21 @@ struct GemmParams {
   void* vt = nullptr;
   int vt_n0 = 0, vt_S = 1;
   int64_t vt_ld = 0;
+  // LayerNorm folded into the weights (linear_stream.hip): y = rstd*(W'x - mean*wsum) + b'
+  int ln_fold = 0;
+  float ln_eps = 1e-5f;
+  const float* wsum = nullptr;
   // batched GEMM (blockIdx.z)
   int batch = 1;
   int64_t sA = 0, sW = 0, sO = 0, sR = 0, sBias = 0;
 };
 
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s);
+// weight-stationary streaming linear for K*sizeof(T) in {640, 1280} bytes (linear_stream.hip)
+bool linear_stream_ok(int dtype, const GemmParams& p);
+int launch_linear_stream(int dtype, const GemmParams& p, hipStream_t s);
+int launch_fold_ln(int dtype, const void* W, int64_t Kp, const float* gamma, const float* beta, const float* bias_in, void* Wo,
+                   float* bias_out, float* wsum, int N, int K, hipStream_t s);
 
 // ---- norms ----
 struct GroupNormParams {

@@ -53,6 +53,10 @@ struct WMat {            // packed GEMM weight [N][Kp] (engine dtype) + fp32 bia
   int N = 0, K = 0, Cin = 0, taps = 1;
   int64_t Kp = 0;
   bool im2col = false;   // 3x3 conv with tiny Cin: K = 9*Cin zero-padded to Kp, A comes from im2col
+  // LayerNorm-folded copy (linear_stream.hip): W' = W*gamma, b' = b + W.beta, wsum[n] = sum_k W'[n][k]
+  void* Wln = nullptr;
+  float* bln = nullptr;
+  float* wsum = nullptr;
 };
 struct WNorm {
   float* g = nullptr;
@@ -165,6 +169,7 @@ class Engine {
   void reg_linear_f32(const std::string& p, int N, int K, WLinF32& w);
   void reg_res(const std::string& p, int cin, int cout, int temb, float eps, ResW& w, bool vae);
   void reg_xf(const std::string& p, int C, int heads, int cross, XfW& w);
+  int fold_ln(WMat& w, const WNorm& ln);
   void build_unet_weights();
   void build_vae_weights();
   void build_voc_weights();

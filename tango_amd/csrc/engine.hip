@@ -35,6 +35,7 @@ struct GOpt {
   void* vt = nullptr;
   int vt_n0 = 0, vt_S = 1;
   int64_t vt_ld = 0;
+  const WNorm* ln = nullptr;     // apply LayerNorm(ln) to the input rows first (folded when the streaming kernel applies)
 };
 
 struct Builder {
@@ -88,7 +89,23 @@ struct Builder {
     p.a_act = o.a_act; p.a_slope = o.a_slope; p.e_act = o.e_act; p.e_slope = o.e_slope; p.epi = o.epi;
     p.bias2 = o.bias2; p.bias2_stride = o.bias2_stride; p.step_ptr = o.bias2 ? E.d_step : nullptr;
     if (o.vt) { p.epi = EPI_VT; p.vt = o.vt; p.vt_n0 = o.vt_n0; p.vt_S = o.vt_S; p.vt_ld = o.vt_ld; }
-    gemm(p, "linear");
+    if (o.ln) {
+      GemmParams q = p;
+      q.W = w.Wln; q.bias = w.bln; q.ln_fold = 1; q.ln_eps = o.ln->eps; q.wsum = w.wsum;
+      if (w.Wln && linear_stream_ok(dt, q)) {
+        gemm(q, "linear+ln(stream)");
+        return;
+      }
+      // fallback: materialise LayerNorm(x), then the plain GEMM
+      const size_t m = A.mark();
+      TView t = alloc(rows, o.ln->C);
+      layernorm(x, rows, *o.ln, t);
+      p.A = t.p; p.lda = t.ld;
+      gemm(p, "linear");
+      A.release(m);
+      return;
+    }
+    gemm(p, linear_stream_ok(dt, p) ? "linear(stream)" : "linear");
   }
 
   // 3x3 conv (pad 1) on NHWC: output grid B x H x W; source B x Hin x Win (nearest-upsampled x2 when ups)
@@ -184,25 +201,21 @@ struct Builder {
     groupnorm(x, B, HW, w.gn, groups, ACT_NONE, t0);
     TView h = alloc(rows, C);
     linear(t0, rows, w.proj_in, h);
-    TView t1 = alloc(rows, C);
-    layernorm(h, rows, w.ln1, t1);
     TView qkv = alloc(rows, 2 * C);                 // [q | k]; v goes transposed into vt [B][C][HW]
     void* vt = A.alloc((size_t)rows * C * esz);
     GOpt nb; nb.use_bias = false;
-    { GOpt o = nb; o.vt = vt; o.vt_n0 = 2 * C; o.vt_S = HW; o.vt_ld = HW; linear(t1, rows, w.qkv, qkv, o); }
+    { GOpt o = nb; o.ln = &w.ln1; o.vt = vt; o.vt_n0 = 2 * C; o.vt_S = HW; o.vt_ld = HW; linear(h, rows, w.qkv, qkv, o); }
     TView a = alloc(rows, C);
     attention(slice(qkv, 0, C, esz), slice(qkv, C, C, esz), vt, HW, a, nullptr, B, w.heads, HW, HW);
     TView h1 = alloc(rows, C);
     { GOpt o; o.residual = &h; linear(a, rows, w.o1, h1, o); }
-    layernorm(h1, rows, w.ln2, t1);
     TView q = slice(qkv, 0, C, esz);   // reuse the qkv buffer for the cross-attention query
-    linear(t1, rows, w.q2, q, nb);
+    { GOpt o = nb; o.ln = &w.ln2; linear(h1, rows, w.q2, q, o); }
     attention(q, kv, kvt, (L + 7) / 8 * 8, a, bias, B, w.heads, HW, L);
     TView h2 = h;                       // h is dead after h1 was produced
     { GOpt o; o.residual = &h1; linear(a, rows, w.o2, h2, o); }
-    layernorm(h2, rows, w.ln3, t1);
     TView gg = alloc(rows, 4 * C);
-    { GOpt o; o.epi = EPI_GEGLU; linear(t1, rows, w.ff1, gg, o); }
+    { GOpt o; o.epi = EPI_GEGLU; o.ln = &w.ln3; linear(h2, rows, w.ff1, gg, o); }
     TView h3 = h1;                      // h1 is dead after h2 was produced
     { GOpt o; o.residual = &h2; linear(gg, rows, w.ff2, h3, o); }
     { GOpt o; o.residual = &x; linear(h3, rows, w.proj_out, out, o); }
@@ -592,9 +605,25 @@ int Engine::set_weight(const char* name, const float* dev, const int64_t* shape,
   return 0;
 }
 
+int Engine::fold_ln(WMat& w, const WNorm& ln) {
+  if (!w.Wln) {
+    w.Wln = dmalloc((size_t)w.N * w.Kp * esz);
+    w.bln = (float*)dmalloc((size_t)w.N * 4);
+    w.wsum = (float*)dmalloc((size_t)w.N * 4);
+    if (!w.Wln || !w.bln || !w.wsum) return -1;
+  }
+  return launch_fold_ln(dt, w.W, w.Kp, ln.g, ln.b, w.b, w.Wln, w.bln, w.wsum, w.N, w.K, 0);
+}
+
 int Engine::finalize_weights() {
   for (auto& s : slots)
     if (!s.set) TANGO_FAIL("finalize_weights: missing key '" + s.name + "'");
+  // fold the three LayerNorms of every BasicTransformerBlock into the projections that consume them
+  for (XfW* x : all_xf) {
+    TANGO_TRY(fold_ln(x->qkv, x->ln1));
+    TANGO_TRY(fold_ln(x->q2, x->ln2));
+    TANGO_TRY(fold_ln(x->ff1, x->ln3));
+  }
   TANGO_HIP(hipDeviceSynchronize());
   finalized = true;
   return 0;

@@ -381,6 +381,8 @@ static int launch_t(const GemmParams& p, hipStream_t s) {
 }
 
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
+  if (linear_stream_ok(dtype, p)) return launch_linear_stream(dtype, p, s);
+  if (p.ln_fold) TANGO_FAIL("gemm: ln_fold is only implemented by the streaming linear kernel");
   switch (dtype) {
     case DT_F32: return launch_t<float>(p, s);
     case DT_F16: return launch_t<f16>(p, s);

@@ -1,0 +1,331 @@
+// Weight-stationary, activation-streaming linear for the small-K transformer GEMMs (K*sizeof(T) = 640 or
+// 1280 bytes: C = 320 / 640 in 16-bit).  At these K the tiled gather-GEMM re-loads a whole weight panel per
+// 128-row tile and is L1/latency-bound (180-300 TFLOP/s); here
+//   * one 512-thread workgroup per CU keeps a [BN x K] weight panel resident in LDS (100 KB, XOR-swizzled),
+//   * each of the 8 waves streams its own 32-row groups of the activation matrix STRAIGHT from HBM into MFMA
+//     B-operand fragments (lane (m, g) owns 16 contiguous bytes of row m), through a 5/10-deep register ring
+//     (loads are issued 5-10 k-steps ahead of their use), with NO barrier in the main loop,
+//   * LayerNorm is folded algebraically: with W' = W*gamma, b' = b + W.beta, wsum[n] = sum_k W'[n][k],
+//       y[m][n] = rstd[m] * (sum_k W'[n][k] x[m][k] - mean[m] * wsum[n]) + b'[n],
+//     so the raw activations feed the MFMA and the row statistics (accumulated from the same fragments)
+//     enter only in the epilogue: the LayerNorm kernel and its write+read round trip disappear
+//     (BasicTransformerBlock norm1/2/3, mustango/diffusers/src/diffusers/models/attention.py:276-335).
+#include "common.h"
+
+namespace tango {
+
+template <typename T> struct SMma;
+template <> struct SMma<float> {
+  __device__ static __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc, 0, 0, 0);
+  }
+};
+template <> struct SMma<f16> {
+  __device__ static __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+  }
+};
+template <> struct SMma<bf16> {
+  __device__ static __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  }
+};
+
+template <typename T> __device__ __forceinline__ void frag_stats(const u32x4& v, float& s, float& q) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  T e[EPV];
+  __builtin_memcpy(e, &v, 16);
+#pragma unroll
+  for (int i = 0; i < EPV; ++i) { const float f = to_f(e[i]); s += f; q += f * f; }
+}
+
+// KS = K*sizeof(T)/64 k-steps per row, TN = 16-column tiles per panel (BN = 16*TN); ring of R = 10 k-steps
+template <typename T, int KS, int TN>
+__global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) {
+  constexpr int R = (TN > 5) ? 5 : 10;         // ring depth in k-steps (register budget: acc 8*TN + ring 8*R)
+  constexpr int TM = 2;
+  constexpr int ROWB = KS * 64;                // bytes per weight row
+  constexpr int BN = TN * 16;
+  static_assert(KS % R == 0, "ring");
+  extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];   // [BN][ROWB], swizzled per 128-byte segment
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  // XCD-aware placement: block b runs on XCD b % 8 (observed round-robin dispatch; speed only).  All NP panels of
+  // one row range sit on the SAME XCD and advance in lockstep, so the activation rows are pulled from HBM/MALL into
+  // that XCD's L2 once and the other NP-1 panels hit L2.
+  const int NP = p.N / BN;                     // panels
+  const int rpx = gridDim.x / (8 * NP);        // row ranges per XCD
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int panel = j % NP, mb = xcd * rpx + j / NP, MB = 8 * rpx;
+  const int n0 = panel * BN;
+
+  // ---- weight panel -> LDS (once per workgroup) ----
+  {
+    const unsigned char* Wp = (const unsigned char*)p.W + (int64_t)n0 * p.Kp * (int64_t)sizeof(T);
+    constexpr int PPRW = ROWB / 16;
+    for (int id = tid; id < BN * PPRW; id += 512) {
+      const int row = id / PPRW, pc = id % PPRW;
+      const u32x4 v = *(const u32x4*)(Wp + (int64_t)row * p.Kp * (int64_t)sizeof(T) + pc * 16);
+      const int seg = pc >> 3, pp = pc & 7;
+      *(u32x4*)(wlds + row * ROWB + seg * 128 + ((pp ^ (row & 7)) * 16)) = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- this workgroup's rows: groups of 32 rows, dealt round-robin to the 8 waves ----
+  const int ngroups = (p.M + 31) / 32;
+  const int gper = (ngroups + MB - 1) / MB;
+  const int g0 = mb * gper, g1 = min(ngroups, g0 + gper);
+  const unsigned char* Ab = (const unsigned char*)p.A;
+  const int64_t ldab = p.lda * (int64_t)sizeof(T);
+
+  // Rows beyond M are clamped to a valid row (their results are dropped in the epilogue), and a wave without a
+  // next group re-reads its current one, so the main loop has NO branches: every load is unconditional.
+  auto row_ptr_c = [&](int grp_, int tm) -> const unsigned char* {
+    int m = grp_ * 32 + tm * 16 + l15;
+    m = m < p.M ? m : p.M - 1;
+    return Ab + (int64_t)m * ldab + g * 16;
+  };
+  u32x4 xf[R][TM];
+  int grp = g0 + wave;
+  const unsigned char* cur[TM];
+  const unsigned char* nxt[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) cur[tm] = row_ptr_c(grp < g1 ? grp : g0, tm);
+#pragma unroll
+  for (int s = 0; s < R; ++s)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) xf[s][tm] = *(const u32x4*)(cur[tm] + s * 64);
+
+  // weight-fragment offsets: row n_local = tn*16 + l15 -> (row & 7) == (lane & 7)
+  const unsigned char* wbase = wlds + l15 * ROWB;
+  const int sw = lane & 7;
+  const float* bias = p.bias;
+  const int g4 = g * 4;
+  auto koff_of = [&](int ks) -> int { return (ks >> 1) * 128 + ((((ks & 1) * 4 + g) ^ sw) * 16); };
+
+  // explicit software pipeline on the LDS side, in micro-steps of H = 5 tiles (10 MFMAs = 160 cycles >= LDS
+  // latency): the 5 weight fragments of micro-step u+1 are read while micro-step u multiplies
+  constexpr int H = 5, NH = TN / H, NU = KS * NH;
+  static_assert(TN % H == 0 && (NU % 2) == 0, "micro-steps");
+  u32x4 wf[2][H];
+#pragma unroll
+  for (int a = 0; a < H; ++a) wf[0][a] = *(const u32x4*)(wbase + a * 16 * ROWB + koff_of(0));
+
+  for (; grp < g1; grp += 8) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) nxt[tm] = row_ptr_c(grp + 8 < g1 ? grp + 8 : grp, tm);
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ssum[TM] = {0.f, 0.f}, ssq[TM] = {0.f, 0.f};
+
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int ks = u / NH, hh = u % NH;
+      const int slot = ks % R;
+      const int cb_ = u & 1, nb_ = cb_ ^ 1;
+      const int un = (u + 1) % NU;                        // next micro-step (wraps to the next group: same weights)
+      const int ksn = un / NH, hn = un % NH;
+#pragma unroll
+      for (int a = 0; a < H; ++a) wf[nb_][a] = *(const u32x4*)(wbase + (hn * H + a) * 16 * ROWB + koff_of(ksn));
+      __builtin_amdgcn_sched_barrier(0);
+      if (p.ln_fold && hh == 0) { frag_stats<T>(xf[slot][0], ssum[0], ssq[0]); frag_stats<T>(xf[slot][1], ssum[1], ssq[1]); }
+#pragma unroll
+      for (int a = 0; a < H; ++a) {
+        SMma<T>::run(acc[hh * H + a][0], wf[cb_][a], xf[slot][0]);
+        SMma<T>::run(acc[hh * H + a][1], wf[cb_][a], xf[slot][1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (hh == NH - 1) {
+        // refill the ring slot with the k-step that is R ahead in this wave's stream
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const unsigned char* src = (ks + R < KS) ? cur[tm] + (ks + R) * 64 : nxt[tm] + (ks + R - KS) * 64;
+          xf[slot][tm] = *(const u32x4*)src;
+        }
+      }
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) cur[tm] = nxt[tm];
+
+    // ---- epilogue for rows grp*32 .. +31, columns n0 .. n0+BN ----
+    float mean[TM] = {0.f, 0.f}, rstd[TM] = {1.f, 1.f};
+    if (p.ln_fold) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        float s = ssum[tm], q = ssq[tm];
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+        const float mu = s / (float)p.K;
+        float var = q / (float)p.K - mu * mu;
+        var = var < 0.f ? 0.f : var;
+        mean[tm] = mu; rstd[tm] = rsqrtf(var + p.ln_eps);
+      }
+    }
+    int64_t orow[TM], vtrow[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = grp * 32 + tm * 16 + l15;
+      orow[tm] = m < p.M ? m : -1; vtrow[tm] = 0;
+      if (p.epi == EPI_VT && m < p.M) {
+        const int bb = m / p.vt_S;
+        vtrow[tm] = (int64_t)bb * (p.N - p.vt_n0) * p.vt_ld + (m - bb * p.vt_S);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+      if (p.epi == EPI_GEGLU && (a & 1)) continue;
+      const int nt = n0 + a * 16;
+      const int n = nt + g4;
+      float cb[4], cw[4], gb[4] = {0.f, 0.f, 0.f, 0.f}, gw[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        cb[r] = bias ? bias[n + r] : 0.f;
+        cw[r] = p.ln_fold ? p.wsum[n + r] : 0.f;
+        if (p.epi == EPI_GEGLU) { gb[r] = bias ? bias[n + 16 + r] : 0.f; gw[r] = p.ln_fold ? p.wsum[n + 16 + r] : 0.f; }
+      }
+      int oc = n;
+      if (p.epi == EPI_GEGLU) oc = (nt >> 1) + g4;
+      const bool to_vt = (p.epi == EPI_VT) && n >= p.vt_n0;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        if (orow[tm] < 0) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rstd[tm] * (acc[a][tm][r] - mean[tm] * cw[r]) + cb[r];
+        if (p.epi == EPI_GEGLU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float gt = rstd[tm] * (acc[a + 1 < TN ? a + 1 : a][tm][r] - mean[tm] * gw[r]) + gb[r];
+            v[r] = v[r] * gelu_erf_f(gt);
+          }
+        }
+        if (p.R) {
+          T rv[4];
+          __builtin_memcpy(rv, (const T*)p.R + orow[tm] * p.ldr + oc, 4 * sizeof(T));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += to_f(rv[r]);
+        }
+        T tv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tv[r] = from_f<T>(v[r]);
+        if (to_vt) {
+          T* vp = (T*)p.vt + vtrow[tm] + (int64_t)(n - p.vt_n0) * p.vt_ld;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vp[(int64_t)r * p.vt_ld] = tv[r];
+        } else {
+          __builtin_memcpy((T*)p.out + orow[tm] * p.ldo + oc, tv, 4 * sizeof(T));
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int KS, int TN>
+static int stream_launch(const GemmParams& p, hipStream_t s) {
+  constexpr int BN = TN * 16;
+  constexpr int LDS = BN * KS * 64;
+  static bool attr_set = false;
+  auto kfn = lin_stream_kernel<T, KS, TN>;
+  if (!attr_set) {
+    TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  const int NP = p.N / BN;
+  int rpx = 32 / NP;               // one workgroup per CU: 32 per XCD = NP panels x rpx row ranges
+  if (rpx < 1) rpx = 1;
+  const int ngroups = (p.M + 31) / 32;
+  while (rpx > 1 && 8 * rpx * 8 > ngroups) --rpx;   // keep >= 8 row groups (one per wave) per workgroup
+  hipLaunchKernelGGL(kfn, dim3((unsigned)(8 * NP * rpx)), dim3(512), LDS, s, p);
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+// can this GEMM run on the streaming kernel?
+bool linear_stream_ok(int dtype, const GemmParams& p) {
+  const int esz = dtype == DT_F32 ? 4 : 2;
+  const int rowb = p.K * esz;
+  if (p.mode != GATHER_1D || p.taps != 1 || p.rows_pb != p.M || p.in_mul != 1 || p.in_off != 0 || p.out_mul != 1 || p.out_off != 0)
+    return false;
+  if (p.batch != 1 || p.bias2 || p.bias_rows || p.out_f32 || p.a_act != ACT_NONE || p.e_act != ACT_NONE || p.alpha != 1.f ||
+      p.out_scale != 1.f)
+    return false;
+  if (p.epi != EPI_NONE && p.epi != EPI_GEGLU && p.epi != EPI_VT) return false;
+  if (p.M < 4096) return false;                     // too few row groups to feed 256 CUs
+  int tn;
+  if (rowb == 640) tn = 10;
+  else if (rowb == 1280) tn = 5;
+  else return false;
+  if (p.N % (16 * tn) != 0) return false;
+  if (p.epi == EPI_GEGLU && (tn & 1)) return false;
+  if (p.epi == EPI_VT && (p.vt_n0 % 16) != 0) return false;
+  if ((p.ldo % 4) || (p.R && (p.ldr % 4))) return false;
+  return true;
+}
+
+template <typename T>
+static int stream_t(const GemmParams& p, hipStream_t s) {
+  const int rowb = p.K * (int)sizeof(T);
+  if (rowb == 640) return stream_launch<T, 10, 10>(p, s);
+  if (rowb == 1280) return stream_launch<T, 20, 5>(p, s);
+  TANGO_FAIL("linear_stream: unsupported K");
+}
+
+int launch_linear_stream(int dtype, const GemmParams& p, hipStream_t s) {
+  switch (dtype) {
+    case DT_F32: return stream_t<float>(p, s);
+    case DT_F16: return stream_t<f16>(p, s);
+    case DT_BF16: return stream_t<bf16>(p, s);
+  }
+  TANGO_FAIL("linear_stream: bad dtype");
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm folding at weight-finalisation time: W'[n][k] = W[n][k] * gamma[k] (rounded to T),
+// b'[n] = b[n] + sum_k W[n][k] beta[k], wsum[n] = sum_k float(W'[n][k]).  One wave per output row.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void fold_ln_kernel(const T* __restrict__ W, int64_t Kp, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ bias_in,
+                                                      T* __restrict__ Wo, float* __restrict__ bias_out, float* __restrict__ wsum,
+                                                      int N, int K) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float sb = 0.f, sw = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = to_f(W[(int64_t)n * Kp + k]);
+    const T wg = from_f<T>(w * gamma[k]);
+    Wo[(int64_t)n * Kp + k] = wg;
+    sb += w * beta[k];
+    sw += to_f(wg);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sb += __shfl_xor(sb, o); sw += __shfl_xor(sw, o); }
+  if (lane == 0) {
+    bias_out[n] = (bias_in ? bias_in[n] : 0.f) + sb;
+    wsum[n] = sw;
+  }
+}
+
+int launch_fold_ln(int dtype, const void* W, int64_t Kp, const float* gamma, const float* beta, const float* bias_in, void* Wo,
+                   float* bias_out, float* wsum, int N, int K, hipStream_t s) {
+  const unsigned nb = (unsigned)((N + 3) / 4);
+  switch (dtype) {
+    case DT_F32: hipLaunchKernelGGL((fold_ln_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)W, Kp, gamma, beta, bias_in, (float*)Wo, bias_out, wsum, N, K); break;
+    case DT_F16: hipLaunchKernelGGL((fold_ln_kernel<f16>), dim3(nb), dim3(256), 0, s, (const f16*)W, Kp, gamma, beta, bias_in, (f16*)Wo, bias_out, wsum, N, K); break;
+    case DT_BF16: hipLaunchKernelGGL((fold_ln_kernel<bf16>), dim3(nb), dim3(256), 0, s, (const bf16*)W, Kp, gamma, beta, bias_in, (bf16*)Wo, bias_out, wsum, N, K); break;
+    default: TANGO_FAIL("fold_ln: bad dtype");
+  }
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace tango

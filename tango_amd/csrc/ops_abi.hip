@@ -136,6 +136,49 @@ int tango_op_linear(int dt, const float* x, const float* w, const float* bias, c
   return 0;
 }
 
+int tango_op_linear_ln(int dt, const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                       const float* residual, float* out, int M, int N, int K, int geglu, float eps, void* stream) {
+  // LayerNorm(x) @ W^T (+bias, GEGLU, +residual): streaming kernel with folded LN when eligible, else LN + GEMM
+  hipStream_t s = (hipStream_t)stream;
+  const size_t esz = dtype_size(dt);
+  Scratch sc;
+  const int No = geglu ? N / 2 : N;
+  void* xt = sc.get((size_t)M * K * esz);
+  void* wt = sc.get((size_t)N * K * esz);
+  void* wl = sc.get((size_t)N * K * esz);
+  void* ot = sc.get((size_t)M * No * esz);
+  void* rt = residual ? sc.get((size_t)M * No * esz) : nullptr;
+  float* bt = (float*)sc.get((size_t)N * 4);
+  float* bl = (float*)sc.get((size_t)N * 4);
+  float* ws = (float*)sc.get((size_t)N * 4);
+  if (!xt || !wt || !wl || !ot || !bt || !bl || !ws) TANGO_FAIL("op_linear_ln: alloc");
+  TANGO_TRY(launch_cast_rows(dt, x, xt, K, M, K, s));
+  TANGO_TRY(launch_pack(dt, w, wt, N, 1, K, K, 0, 1, K, geglu ? -1 : 0, s));
+  if (residual) TANGO_TRY(launch_cast_rows(dt, residual, rt, No, M, No, s));
+  if (bias) {
+    if (geglu) TANGO_TRY(launch_permute_geglu_bias(bias, bt, N, s));
+    else TANGO_HIP(hipMemcpyAsync(bt, bias, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+  }
+  TANGO_TRY(launch_fold_ln(dt, wt, K, gamma, beta, bias ? bt : nullptr, wl, bl, ws, N, K, s));
+  GemmParams p;
+  p.A = xt; p.lda = K; p.W = wl; p.Kp = K; p.bias = bl; p.M = M; p.N = N; p.K = K; p.Cin = K;
+  p.mode = GATHER_1D; p.rows_pb = M; p.Lin = M; p.Lout = M;
+  p.out = ot; p.ldo = No; p.R = rt; p.ldr = No; p.epi = geglu ? EPI_GEGLU : EPI_NONE;
+  p.ln_fold = 1; p.ln_eps = eps; p.wsum = ws;
+  if (linear_stream_ok(dt, p)) {
+    TANGO_TRY(launch_gemm(dt, p, s));
+  } else {
+    void* nt = sc.get((size_t)M * K * esz);
+    if (!nt) TANGO_FAIL("op_linear_ln: alloc");
+    TANGO_TRY(launch_layernorm(dt, xt, K, nt, K, gamma, beta, M, K, eps, s));
+    p.A = nt; p.W = wt; p.bias = bias ? bt : nullptr; p.ln_fold = 0; p.wsum = nullptr;
+    TANGO_TRY(launch_gemm(dt, p, s));
+  }
+  TANGO_TRY(to_f32(dt, ot, No, out, M, No, s));
+  TANGO_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 int tango_op_conv1d(int dt, const float* x, const float* w, const float* bias, const float* residual, float* out, int B, int Cin,
                     int L, int Cout, int k, int dilation, int a_act, float a_slope, int e_act, float e_slope, void* stream) {
   hipStream_t s = (hipStream_t)stream;

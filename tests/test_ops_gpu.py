@@ -86,6 +86,48 @@ def test_linear_geglu(lib, dtype):
     close(out, val * F.gelu(gate), dtype, "geglu")
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("M,N,K,geglu,res", [(4128, 320, 320, 0, 1), (8192, 960, 320, 0, 0), (4100, 2560, 320, 1, 0), (4096, 640, 640, 0, 1),
+                                             (5000, 1920, 640, 0, 0), (4096, 320, 1280, 0, 1), (300, 320, 320, 0, 0)])
+def test_linear_layernorm_fused(lib, dtype, M, N, K, geglu, res):
+    """weight-stationary streaming linear (K*sizeof(T) in {640,1280} B, M >= 4096) with LayerNorm folded into the
+    weights vs LayerNorm -> Linear (-> GEGLU) (+ residual); other shapes take the LN-kernel + GEMM fallback"""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = quant(torch.randn(M, K, generator=g) * 1.3 + 0.7, dtype)
+    w = quant(torch.randn(N, K, generator=g) / K ** 0.5, dtype)
+    b = torch.randn(N, generator=g)
+    ga, be = 1 + 0.2 * torch.randn(K, generator=g), 0.3 * torch.randn(K, generator=g)
+    No = N // 2 if geglu else N
+    r = quant(torch.randn(M, No, generator=g), dtype) if res else None
+    h = F.linear(F.layer_norm(x, (K,), ga, be, 1e-5), w, b)
+    if geglu:
+        v, gt = h.chunk(2, dim=-1)
+        h = v * F.gelu(gt)
+    ref = h + r if res else h
+    out = torch.empty(M, No, device="cuda")
+    check(lib, lib.tango_op_linear_ln(DT[dtype], ptr(dev(x)), ptr(dev(w)), ptr(dev(b)), ptr(dev(ga)), ptr(dev(be)),
+                                      ptr(dev(r)) if res else None, ptr(out), M, N, K, geglu, 1e-5, None))
+    ref = ref.float()
+    scale = ref.abs().max().item()
+    err = (out.cpu() - ref).abs().max().item() / scale
+    # the folded form keeps x un-normalised in T: its rounding is relative to |x| (not |x - mean|), so allow 2x
+    assert err <= 2 * TOL[dtype], "linear_ln rel err %.3e" % err
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_linear_stream_plain(lib, dtype):
+    """same kernel without LayerNorm: bias + residual, M not a multiple of 32"""
+    M, N, K = 4130, 320, 320
+    g = torch.Generator().manual_seed(9)
+    x = quant(torch.randn(M, K, generator=g), dtype)
+    w = quant(torch.randn(N, K, generator=g) / K ** 0.5, dtype)
+    b = torch.randn(N, generator=g)
+    r = quant(torch.randn(M, N, generator=g), dtype)
+    out = torch.empty(M, N, device="cuda")
+    check(lib, lib.tango_op_linear(DT[dtype], ptr(dev(x)), ptr(dev(w)), ptr(dev(b)), ptr(dev(r)), ptr(out), M, N, K, 0, 0, 0, None))
+    close(out, F.linear(x, w, b) + r, dtype, "linear stream")
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
 @pytest.mark.parametrize("Cin,Cout,H,W,stride,ups", [(64, 64, 16, 8, 1, 0), (64, 96, 16, 8, 2, 0), (64, 32, 8, 4, 1, 1),
                                                     (8, 64, 16, 16, 1, 0), (128, 160, 6, 2, 1, 0), (32, 8, 16, 4, 1, 0)])

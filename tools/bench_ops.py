@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Micro-benchmark of single engine ops through the C ABI (for rocprofv3 --pmc runs).
+usage: python tools/bench_ops.py linear M N K [reps]   |   conv B C H W Cout [reps]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from tango_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+kind = sys.argv[1]
+p = lambda t: C.c_void_p(t.data_ptr())
+if kind == "linear":
+    M, N, K = [int(v) for v in sys.argv[2:5]]
+    reps = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+    x = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") / K ** 0.5
+    b = torch.randn(N, device="cuda")
+    r = torch.randn(M, N, device="cuda")
+    out = torch.empty(M, N, device="cuda")
+    for _ in range(reps):
+        assert lib.tango_op_linear(1, p(x), p(w), p(b), p(r), p(out), M, N, K, 0, 0, 0, None) == 0
+elif kind == "conv":
+    B, Cc, H, W, Co = [int(v) for v in sys.argv[2:7]]
+    reps = int(sys.argv[7]) if len(sys.argv) > 7 else 5
+    x = torch.randn(B, Cc, H, W, device="cuda")
+    w = torch.randn(Co, Cc, 3, 3, device="cuda") / (9 * Cc) ** 0.5
+    b = torch.randn(Co, device="cuda")
+    out = torch.empty(B, Co, H, W, device="cuda")
+    for _ in range(reps):
+        assert lib.tango_op_conv2d(1, p(x), p(w), p(b), p(out), B, Cc, H, W, Co, 1, 0, None) == 0
+torch.cuda.synchronize()
+print("done")
