@@ -122,12 +122,18 @@ struct GemmParams {
   int ln_fold = 0;
   float ln_eps = 1e-5f;
   const float* wsum = nullptr;
+  // split-K (small-M GEMMs that cannot fill 256 CUs): blockIdx.y = split; raw fp32 partials go to
+  // ws[split][M][N], a second kernel sums them in fixed order (deterministic) and applies the epilogue
+  int splitk = 1;
+  float* ws = nullptr;
   // batched GEMM (blockIdx.z)
   int batch = 1;
   int64_t sA = 0, sW = 0, sO = 0, sR = 0, sBias = 0;
 };
 
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s);
+// split-K factor the launcher wants for this problem (1 = none); caller provides ws = splitk*M*N floats
+int gemm_pick_splitk(int dtype, const GemmParams& p);
 // weight-stationary streaming linear for K*sizeof(T) in {640, 1280} bytes (linear_stream.hip)
 bool linear_stream_ok(int dtype, const GemmParams& p);
 int launch_linear_stream(int dtype, const GemmParams& p, hipStream_t s);

@@ -69,10 +69,17 @@ struct Builder {
       prog->flops.push_back(fl);
     }
   }
-  void gemm(const GemmParams& p, const char* what = "gemm") {
+  void gemm(GemmParams p, const char* what = "gemm") {
     const int d = dt;
+    const int sk = gemm_pick_splitk(d, p);
+    if (sk > 1) {   // the workspace may alias later temporaries: the whole program is stream-ordered
+      const size_t m = A.mark();
+      p.splitk = sk;
+      p.ws = alloc_f32((size_t)sk * p.M * p.N);
+      A.release(m);
+    }
     char buf[160];
-    snprintf(buf, sizeof buf, "%s M=%d N=%d K=%d%s", what, p.M, p.N, p.K, p.batch > 1 ? " batched" : "");
+    snprintf(buf, sizeof buf, "%s M=%d N=%d K=%d%s%s", what, p.M, p.N, p.K, p.batch > 1 ? " batched" : "", sk > 1 ? " splitK" : "");
     push([p, d](hipStream_t s) { return launch_gemm(d, p, s); }, buf, 2.0 * p.M * (double)p.N * p.K * p.batch);
   }
 

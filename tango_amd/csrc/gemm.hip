@@ -129,7 +129,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 ar[AP], br[BP];
-  const int nk = p.K / BK;
+  int kc_begin = 0, nk = p.K / BK;
+  if (p.splitk > 1) {
+    const int per = (nk + p.splitk - 1) / p.splitk;
+    kc_begin = blockIdx.y * per;
+    nk = min(nk, kc_begin + per);
+  }
 
   auto load_chunk = [&](int kc) {
     const int k0 = kc * BK;
@@ -195,10 +200,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const int xrow = (wm * WMR + (lane & 15)) * LDSR;
   const int wrow = (wn * WNR + (lane & 15)) * LDSR;
 
-  load_chunk(0);
-  store_stage(0);
+  if (kc_begin < nk) {
+    load_chunk(kc_begin);
+    store_stage(kc_begin & 1);
+  }
   __syncthreads();
-  for (int kc = 0; kc < nk; ++kc) {
+  for (int kc = kc_begin; kc < nk; ++kc) {
     const bool more = kc + 1 < nk;
     if (more) load_chunk(kc + 1);
     const unsigned char* Xs = smem + (kc & 1) * STAGE;
@@ -221,6 +228,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 
   // ---------------- epilogue ----------------
   const int g4 = (lane >> 4) * 4;
+  if (p.splitk > 1) {   // raw fp32 partial tile -> workspace; the reduce kernel finishes the job
+    float* wsb = p.ws + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      const int m = m0 + wm * WMR + b * 16 + (lane & 15);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int a = 0; a < TN; ++a) {
+        const int n = n0 + wn * WNR + a * 16 + g4;
+        if (n + 3 < p.N) *(f32x4*)(wsb + (int64_t)m * p.N + n) = acc[a][b];
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n + r < p.N) wsb[(int64_t)m * p.N + n + r] = acc[a][b][r];
+        }
+      }
+    }
+    return;
+  }
   const float* bias = p.bias ? p.bias + (int64_t)blockIdx.z * p.sBias : nullptr;
   const float* bias2 = nullptr;
   if (p.bias2) bias2 = p.bias2 + (int64_t)(p.step_ptr ? *p.step_ptr : 0) * p.bias2_stride;
@@ -338,9 +363,54 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   }
 }
 
+// sums the split-K partials in split order and applies the epilogue (bias, per-step bias, activation, residual)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = p.N / 4;
+  if (idx >= (int64_t)p.M * n4) return;
+  const int64_t m = idx / n4;
+  const int n = (int)(idx - m * n4) * 4;
+  f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < p.splitk; ++s) a += *(const f32x4*)(p.ws + ((int64_t)s * p.M + m) * p.N + n);
+  const float* bias2 = p.bias2 ? p.bias2 + (int64_t)(p.step_ptr ? *p.step_ptr : 0) * p.bias2_stride : nullptr;
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float x = a[r] * p.alpha;
+    if (p.bias) x += p.bias[n + r];
+    if (bias2) x += bias2[n + r];
+    if (p.e_act != ACT_NONE) x = apply_act(x, p.e_act, p.e_slope);
+    v[r] = x;
+  }
+  if (p.R) {
+    T rv[4];
+    __builtin_memcpy(rv, (const T*)p.R + m * p.ldr + n, 4 * sizeof(T));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += to_f(rv[r]);
+  }
+  if (p.out_f32) {
+    *(f32x4*)((float*)p.out + m * p.ldo + n) = f32x4{v[0], v[1], v[2], v[3]};
+  } else {
+    T tv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tv[r] = from_f<T>(v[r]);
+    __builtin_memcpy((T*)p.out + m * p.ldo + n, tv, 4 * sizeof(T));
+  }
+}
+
 template <typename T, int BM, int BN, int BKB, int WM, int WN, int MODE>
 static int launch_cfg(const GemmParams& p, hipStream_t s) {
   const int MT = (p.M + BM - 1) / BM, NT = (p.N + BN - 1) / BN;
+  if (p.splitk > 1) {
+    if (!p.ws) TANGO_FAIL("gemm: split-K needs a workspace");
+    dim3 grid((unsigned)(MT * NT), (unsigned)p.splitk, 1);
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, BKB, WM, WN, MODE>), grid, dim3(256), 0, s, p);
+    const int64_t work = (int64_t)p.M * (p.N / 4);
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, p);
+    TANGO_HIP(hipGetLastError());
+    return 0;
+  }
   dim3 grid((unsigned)(MT * NT), 1, (unsigned)p.batch);
   hipLaunchKernelGGL((gemm_kernel<T, BM, BN, BKB, WM, WN, MODE>), grid, dim3(256), 0, s, p);
   TANGO_HIP(hipGetLastError());
@@ -378,6 +448,26 @@ static int launch_t(const GemmParams& p, hipStream_t s) {
   if (cb % 128 == 0) return launch_mode<T, 128>(p, s);
   if (cb % 64 == 0) return launch_mode<T, 64>(p, s);
   TANGO_FAIL("gemm: Cin*sizeof(T) must be a multiple of 64 bytes");
+}
+
+// Split-K policy: only plain-epilogue linear / conv2d problems whose 128x160 tiling leaves most CUs idle.
+int gemm_pick_splitk(int dtype, const GemmParams& p) {
+  if (p.batch != 1 || p.epi != EPI_NONE || p.bias_rows || p.out_scale != 1.f || (p.N & 3) || (p.ldo & 3) || (p.R && (p.ldr & 3)))
+    return 1;
+  if (p.mode == GATHER_1D && !(p.taps == 1 && p.rows_pb == p.M && p.in_mul == 1 && p.in_off == 0 && p.out_mul == 1 && p.out_off == 0))
+    return 1;
+  if (linear_stream_ok(dtype, p)) return 1;
+  const int esz = dtype == DT_F32 ? 4 : 2;
+  const int bk = ((p.Cin * esz) % 128 == 0) ? 128 / esz : 64 / esz;
+  const int nk = p.K / bk;
+  const int bn = (p.N % 160 == 0) ? 160 : (p.N >= 96 ? 128 : (p.N > 32 ? 64 : 32));
+  const int bm = p.N > 32 ? 128 : 256;
+  const int tiles = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+  if (tiles >= 400) return 1;
+  int s = (512 + tiles / 2) / tiles;   // aim for ~2 workgroups per CU
+  if (s > nk / 6) s = nk / 6;     // keep >= 6 k-chunks per split
+  if (s > 32) s = 32;
+  return s < 2 ? 1 : s;
 }
 
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {

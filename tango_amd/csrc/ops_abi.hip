@@ -65,6 +65,17 @@ static int transpose_v(int dt, const void* v, void* vt, int B, int S, int C, int
 
 using namespace tango;
 
+// test wrappers honour the same split-K policy as the engine plans
+static int run_gemm(int dt, GemmParams& p, Scratch& sc, hipStream_t s) {
+  const int sk = gemm_pick_splitk(dt, p);
+  if (sk > 1) {
+    p.splitk = sk;
+    p.ws = (float*)sc.get((size_t)sk * p.M * p.N * 4);
+    if (!p.ws) TANGO_FAIL("run_gemm: alloc");
+  }
+  return launch_gemm(dt, p, s);
+}
+
 extern "C" {
 
 int tango_op_conv2d(int dt, const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W, int Cout,
@@ -101,7 +112,7 @@ int tango_op_conv2d(int dt, const float* x, const float* w, const float* bias, f
     p.A = xt; p.lda = cpad; p.W = wt; p.Kp = Kp; p.M = B * Ho * Wo; p.K = 9 * Cin; p.Cin = Cin;
     p.mode = GATHER_2D; p.H = Ho; p.Wd = Wo; p.Hin = H; p.Win = W; p.stride = stride; p.ups = upsample;
   }
-  TANGO_TRY(launch_gemm(dt, p, s));
+  TANGO_TRY(run_gemm(dt, p, sc, s));
   TANGO_TRY(launch_nhwc_to_nchw_f32(dt, ot, Cout, out, B, Cout, Ho * Wo, s));
   TANGO_HIP(hipStreamSynchronize(s));
   return 0;
@@ -130,7 +141,7 @@ int tango_op_linear(int dt, const float* x, const float* w, const float* bias, c
   p.A = xt; p.lda = K; p.W = wt; p.Kp = K; p.bias = bt; p.M = M; p.N = N; p.K = K; p.Cin = K;
   p.mode = GATHER_1D; p.rows_pb = M; p.Lin = M; p.Lout = M;
   p.out = ot; p.ldo = No; p.R = rt; p.ldr = No; p.a_act = a_act; p.e_act = e_act; p.epi = geglu ? EPI_GEGLU : EPI_NONE;
-  TANGO_TRY(launch_gemm(dt, p, s));
+  TANGO_TRY(run_gemm(dt, p, sc, s));
   TANGO_TRY(to_f32(dt, ot, No, out, M, No, s));
   TANGO_HIP(hipStreamSynchronize(s));
   return 0;

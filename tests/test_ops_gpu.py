@@ -73,6 +73,36 @@ def test_linear(lib, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("M,N,K", [(128, 1280, 5120), (512, 640, 2560), (100, 320, 1280)])
+def test_linear_splitk(lib, dtype, M, N, K):
+    """small-M problems take the deterministic split-K path (partials + fixed-order reduce + epilogue)"""
+    g = torch.Generator().manual_seed(M + N)
+    x = quant(torch.randn(M, K, generator=g), dtype)
+    w = quant(torch.randn(N, K, generator=g) / K ** 0.5, dtype)
+    b = torch.randn(N, generator=g)
+    r = quant(torch.randn(M, N, generator=g), dtype)
+    out = torch.empty(M, N, device="cuda")
+    out2 = torch.empty(M, N, device="cuda")
+    check(lib, lib.tango_op_linear(DT[dtype], ptr(dev(x)), ptr(dev(w)), ptr(dev(b)), ptr(dev(r)), ptr(out), M, N, K, 0, 1, 0, None))
+    check(lib, lib.tango_op_linear(DT[dtype], ptr(dev(x)), ptr(dev(w)), ptr(dev(b)), ptr(dev(r)), ptr(out2), M, N, K, 0, 1, 0, None))
+    close(out, F.silu(F.linear(x, w, b)) + r, dtype, "linear split-K")
+    assert torch.equal(out, out2), "split-K must be run-to-run deterministic"
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_conv2d_splitk(lib, dtype):
+    B, Cin, Cout, H, W = 2, 1280, 320, 8, 2
+    g = torch.Generator().manual_seed(77)
+    x = quant(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = quant(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5, dtype)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b, padding=1)
+    out = torch.empty(ref.shape, device="cuda")
+    check(lib, lib.tango_op_conv2d(DT[dtype], ptr(dev(x)), ptr(dev(w)), ptr(dev(b)), ptr(out), B, Cin, H, W, Cout, 1, 0, None))
+    close(out, ref, dtype, "conv2d split-K")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
 def test_linear_geglu(lib, dtype):
     M, C = 150, 64
     g = torch.Generator().manual_seed(5)
