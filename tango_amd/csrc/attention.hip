@@ -40,8 +40,8 @@ template <> struct AMma<bf16> {
   }
 };
 
-template <typename T, int QB>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
+template <typename T, int QB, bool MASKED>
+__global__ __launch_bounds__(256, 3) void attn_kernel(const AttnParams p) {
   constexpr int EPV = 16 / (int)sizeof(T);
   constexpr int D = 64, KVT = 64;
   constexpr bool HALF = sizeof(T) == 2;
@@ -155,15 +155,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     }
 
     // ---- online softmax in the exp2 domain (per lane: one q column, 16 kv values per q block) ----
-    float bv[4][4];
-    const bool tail = (kv0 + KVT > p.Skv);
-    if (bias || tail) {
+    // MASKED == false: self-attention with Skv a multiple of 64 (no bias, no tail) -> no per-key offsets at all
+    float bv[MASKED ? 4 : 1][4];
+    if (MASKED) {
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int kv = kv0 + kb * 16 + g * 4 + r;
-          bv[kb][r] = (kv < p.Skv) ? (bias ? bias[kv] * LOG2E : 0.f) : -1.0e30f;
+          bv[MASKED ? kb : 0][r] = (kv < p.Skv) ? (bias ? bias[kv] * LOG2E : 0.f) : -1.0e30f;
         }
     }
 #pragma unroll
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float sv = sacc[qb][kb][r] * sc2;
-          if (bias || tail) sv += bv[kb][r];
+          if (MASKED) sv += bv[MASKED ? kb : 0][r];
           sacc[qb][kb][r] = sv;
           mt = fmaxf(mt, sv);
         }
@@ -258,14 +258,17 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
   if ((p.ldq * (int64_t)sizeof(T)) % 16 || (p.ldk * (int64_t)sizeof(T)) % 16 || (p.ldvt * (int64_t)sizeof(T)) % 16 ||
       (p.ldo * (int64_t)sizeof(T)) % 8)
     TANGO_FAIL("attention: ld alignment");
+  const bool masked = p.bias != nullptr || (p.Skv % 64) != 0;
   if (p.Sq > 512) {
     constexpr int QB = 2;
     dim3 grid((unsigned)((p.Sq + 64 * QB - 1) / (64 * QB)), (unsigned)p.heads, (unsigned)p.B);
-    hipLaunchKernelGGL((attn_kernel<T, QB>), grid, dim3(256), 0, s, p);
+    if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_kernel<T, QB, false>), grid, dim3(256), 0, s, p);
   } else {
     constexpr int QB = 1;
     dim3 grid((unsigned)((p.Sq + 64 * QB - 1) / (64 * QB)), (unsigned)p.heads, (unsigned)p.B);
-    hipLaunchKernelGGL((attn_kernel<T, QB>), grid, dim3(256), 0, s, p);
+    if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_kernel<T, QB, false>), grid, dim3(256), 0, s, p);
   }
   TANGO_HIP(hipGetLastError());
   return 0;
