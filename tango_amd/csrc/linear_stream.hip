@@ -10,6 +10,8 @@
 //     so the raw activations feed the MFMA and the row statistics (accumulated from the same fragments)
 //     enter only in the epilogue: the LayerNorm kernel and its write+read round trip disappear
 //     (BasicTransformerBlock norm1/2/3, mustango/diffusers/src/diffusers/models/attention.py:276-335).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace tango {
@@ -251,6 +253,8 @@ static int stream_launch(const GemmParams& p, hipStream_t s) {
 
 // can this GEMM run on the streaming kernel?
 bool linear_stream_ok(int dtype, const GemmParams& p) {
+  static const bool off = getenv("TANGO_NO_STREAM") != nullptr;   // experiment switch (plain linears only)
+  if (off && !p.ln_fold) return false;
   const int esz = dtype == DT_F32 ? 4 : 2;
   const int rowb = p.K * esz;
   if (p.mode != GATHER_1D || p.taps != 1 || p.rows_pb != p.M || p.in_mul != 1 || p.in_off != 0 || p.out_mul != 1 || p.out_off != 0)

@@ -16,13 +16,14 @@ p = lambda t: C.c_void_p(t.data_ptr())
 if kind == "linear":
     M, N, K = [int(v) for v in sys.argv[2:5]]
     reps = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+    use_res = (sys.argv[6] != "nores") if len(sys.argv) > 6 else True
     x = torch.randn(M, K, device="cuda")
     w = torch.randn(N, K, device="cuda") / K ** 0.5
     b = torch.randn(N, device="cuda")
     r = torch.randn(M, N, device="cuda")
     out = torch.empty(M, N, device="cuda")
     for _ in range(reps):
-        assert lib.tango_op_linear(1, p(x), p(w), p(b), p(r), p(out), M, N, K, 0, 0, 0, None) == 0
+        assert lib.tango_op_linear(1, p(x), p(w), p(b), p(r) if use_res else None, p(out), M, N, K, 0, 0, 0, None) == 0
 elif kind == "conv":
     B, Cc, H, W, Co = [int(v) for v in sys.argv[2:7]]
     reps = int(sys.argv[7]) if len(sys.argv) > 7 else 5
