@@ -32,6 +32,9 @@ GFLOP_VAE_PER_SAMPLE = 670.47
 GFLOP_VOCODER_PER_SAMPLE = 1027.04
 AUDIO_SECONDS_PER_SAMPLE = 163872 / 16000.0
 PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
+#: HBM-side bytes of one UNet-step launch at B=32 fp16 from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+#: WRITE_SIZE, KiB units), measured offline: profiles/r1_final_pmc_hbm_traffic_unet_step.txt.  Scales ~linearly with B.
+HBM_BYTES_PER_STEP_B32_FP16 = 186.9e9
 
 
 def parse():
@@ -182,7 +185,8 @@ def main():
                        "global_batch": Bg, "text_len": L, "denoise_steps": args.denoise_steps, "parallelism": "dp%d" % world,
                        "hipgraph": not args.no_graph},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                         "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": None,
+                         "frac": ach / PEAK_TFLOPS[args.dtype],
+                         "traffic": (HBM_BYTES_PER_STEP_B32_FP16 if (B == 32 and args.dtype == "fp16" and not args.xl) else None),
                          "kernel": "UNet denoise step (one hipGraph replay = %d prompts x 1606.36 GFLOP), %.2f ms/launch by HIP events"
                                    % (B, per_step_ms)},
             "end_to_end_tflops": (GFLOP_UNET_PER_PROMPT_STEP * args.denoise_steps + GFLOP_VAE_PER_SAMPLE + GFLOP_VOCODER_PER_SAMPLE)

@@ -132,6 +132,7 @@ struct GemmParams {
 };
 
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s);
+int gemm_init();   // process-wide one-time setup (zero page); call before any launch and outside stream capture
 // split-K factor the launcher wants for this problem (1 = none); caller provides ws = splitk*M*N floats
 int gemm_pick_splitk(int dtype, const GemmParams& p);
 // weight-stationary streaming linear for K*sizeof(T) in {640, 1280} bytes (linear_stream.hip)

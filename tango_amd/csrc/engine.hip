@@ -572,6 +572,7 @@ void Engine::build_voc_weights() {
 
 int Engine::init() {
   if (dt != DT_F32 && dt != DT_F16 && dt != DT_BF16) TANGO_FAIL("engine: bad dtype");
+  TANGO_TRY(gemm_init());
   if (cfg.unet_levels > 0) {
     for (int i = 0; i < cfg.unet_levels; ++i)
       if (cfg.unet_channels[i] != cfg.unet_heads[i] * 64) TANGO_FAIL("engine: UNet channels must equal heads * 64 (head_dim 64)");

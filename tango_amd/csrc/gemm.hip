@@ -657,16 +657,22 @@ static bool gemm_dma_ok(int dtype, const GemmParams& p) {
 
 template <typename T>
 static int launch_dma(const GemmParams& p, hipStream_t s) {
-  if (!g_zero_page) {
-    TANGO_HIP(hipMalloc((void**)&g_zero_page, 4096));
-    TANGO_HIP(hipMemset(g_zero_page, 0, 4096));
-  }
+  if (!g_zero_page) TANGO_FAIL("gemm: gemm_init() was not called (zero page for the LDS-DMA gather)");
   const bool linear = p.mode == GATHER_1D && p.taps == 1 && p.rows_pb == p.M && p.in_mul == 1 && p.in_off == 0 &&
                       p.out_mul == 1 && p.out_off == 0 && p.Lin >= p.M;
   const bool bn128 = (p.epi == EPI_GEGLU || p.N % 160 != 0);
   if (p.mode == GATHER_2D) return bn128 ? launch_dma_cfg<T, 128, MODE_CONV2D>(p, s) : launch_dma_cfg<T, 160, MODE_CONV2D>(p, s);
   if (linear) return bn128 ? launch_dma_cfg<T, 128, MODE_LINEAR>(p, s) : launch_dma_cfg<T, 160, MODE_LINEAR>(p, s);
   return bn128 ? launch_dma_cfg<T, 128, MODE_CONV1D>(p, s) : launch_dma_cfg<T, 160, MODE_CONV1D>(p, s);
+}
+
+// one-time process-wide setup; must run OUTSIDE stream capture (hipMalloc / hipMemset are illegal while capturing)
+int gemm_init() {
+  if (!g_zero_page) {
+    TANGO_HIP(hipMalloc((void**)&g_zero_page, 4096));
+    TANGO_HIP(hipMemset(g_zero_page, 0, 4096));
+  }
+  return 0;
 }
 
 // Split-K policy: only plain-epilogue linear / conv2d problems whose 128x160 tiling leaves most CUs idle.

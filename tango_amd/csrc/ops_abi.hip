@@ -67,6 +67,7 @@ using namespace tango;
 
 // test wrappers honour the same split-K policy as the engine plans
 static int run_gemm(int dt, GemmParams& p, Scratch& sc, hipStream_t s) {
+  TANGO_TRY(gemm_init());
   const int sk = gemm_pick_splitk(dt, p);
   if (sk > 1) {
     p.splitk = sk;
@@ -176,6 +177,7 @@ int tango_op_linear_ln(int dt, const float* x, const float* w, const float* bias
   p.mode = GATHER_1D; p.rows_pb = M; p.Lin = M; p.Lout = M;
   p.out = ot; p.ldo = No; p.R = rt; p.ldr = No; p.epi = geglu ? EPI_GEGLU : EPI_NONE;
   p.ln_fold = 1; p.ln_eps = eps; p.wsum = ws;
+  TANGO_TRY(gemm_init());
   if (linear_stream_ok(dt, p)) {
     TANGO_TRY(launch_gemm(dt, p, s));
   } else {
@@ -208,7 +210,7 @@ int tango_op_conv1d(int dt, const float* x, const float* w, const float* bias, c
   p.mode = GATHER_1D; p.rows_pb = L; p.Lin = L; p.taps = k; p.tap_step = dilation; p.in_off = -dilation * (k - 1) / 2;
   p.Lout = L; p.out = ot; p.ldo = Cout; p.R = rt; p.ldr = Cout;
   p.a_act = a_act; p.a_slope = a_slope; p.e_act = e_act; p.e_slope = e_slope;
-  TANGO_TRY(launch_gemm(dt, p, s));
+  TANGO_TRY(run_gemm(dt, p, sc, s));
   TANGO_TRY(launch_nhwc_to_nchw_f32(dt, ot, Cout, out, B, Cout, L, s));
   TANGO_HIP(hipStreamSynchronize(s));
   return 0;
@@ -239,7 +241,7 @@ int tango_op_conv_transpose1d(int dt, const float* x, const float* w, const floa
     p.mode = GATHER_1D; p.rows_pb = Q; p.Lin = L; p.taps = T; p.tap_step = -1; p.in_off = qmin;
     p.Lout = Lo; p.out_mul = u; p.out_off = u * qmin + r - pd; p.out = ot; p.ldo = Cout;
     p.a_act = a_act; p.a_slope = a_slope;
-    TANGO_TRY(launch_gemm(dt, p, s));
+    TANGO_TRY(run_gemm(dt, p, sc, s));
   }
   TANGO_TRY(launch_nhwc_to_nchw_f32(dt, ot, Cout, out, B, Cout, Lo, s));
   TANGO_HIP(hipStreamSynchronize(s));
