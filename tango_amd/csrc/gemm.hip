@@ -690,7 +690,8 @@ int gemm_pick_splitk(int dtype, const GemmParams& p) {
   const int tiles = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
   if (tiles >= 400) return 1;
   int s = (512 + tiles / 2) / tiles;   // aim for ~2 workgroups per CU
-  if (s > nk / 6) s = nk / 6;     // keep >= 6 k-chunks per split
+  static const int minch = getenv("TANGO_SPLITK_MINCHUNKS") ? atoi(getenv("TANGO_SPLITK_MINCHUNKS")) : 3;
+  if (s > nk / minch) s = nk / minch;     // keep >= minch k-chunks per split
   if (s > 32) s = 32;
   return s < 2 ? 1 : s;
 }

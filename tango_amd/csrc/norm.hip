@@ -6,6 +6,9 @@
 
 namespace tango {
 
+__device__ __forceinline__ float wave_sum(float v);
+__device__ __forceinline__ float wave_max(float v);
+
 static constexpr int GN_NV = 3;      // max 16B vectors per thread per row
 static constexpr int GN_MAXC = 4096;
 
@@ -174,6 +177,74 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
+// Small tensors (L2-resident; B = 1 latency path): ONE kernel, one 1024-thread workgroup per (sample, group).  The group's
+// rows x cg slice is read ONCE as element pairs into registers (<= GNS_NP pairs per thread, all loads in flight together),
+// reduced through LDS, then normalised + affine + SiLU straight from registers.  Replaces three launches that are pure
+// launch latency at this size.
+static constexpr int GNS_NP = 24;
+template <typename T> struct Pair;
+template <> struct Pair<float> { using type = f32x2; };
+template <> struct Pair<_Float16> { using type = uint32_t; };
+template <> struct Pair<__bf16> { using type = uint32_t; };
+
+template <typename T>
+__global__ __launch_bounds__(1024) void gn_fused_small_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              int rows, int C, int groups, float eps, int act) {
+  using P = typename Pair<T>::type;
+  __shared__ float red[2][16];
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int cg = C / groups, hp = cg >> 1;  // pairs per row of this group
+  const int n = rows * hp;
+  const T* xb = x + (int64_t)b * rows * ldx + g * cg;
+  float v[GNS_NP][2];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int i = 0; i < GNS_NP; ++i) {
+    const int e = tid + i * 1024;
+    v[i][0] = 0.f; v[i][1] = 0.f;
+    if (e < n) {
+      const int r = e / hp, c = (e - r * hp) * 2;
+      const P pv = *(const P*)(xb + (int64_t)r * ldx + c);
+      T t2[2];
+      __builtin_memcpy(t2, &pv, sizeof(P));
+      v[i][0] = to_f(t2[0]); v[i][1] = to_f(t2[1]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < GNS_NP; ++i) { s += v[i][0] + v[i][1]; q += v[i][0] * v[i][0] + v[i][1] * v[i][1]; }
+  s = wave_sum(s); q = wave_sum(q);
+  if (lane == 0) { red[0][w] = s; red[1][w] = q; }
+  __syncthreads();
+  double S = 0.0, Q = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { S += (double)red[0][i]; Q += (double)red[1][i]; }
+  const double nn = (double)rows * cg;
+  const double mean = S / nn;
+  double var = Q / nn - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float mu = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+  T* yb = y + (int64_t)b * rows * ldy + g * cg;
+#pragma unroll
+  for (int i = 0; i < GNS_NP; ++i) {
+    const int e = tid + i * 1024;
+    if (e < n) {
+      const int r = e / hp, c = (e - r * hp) * 2;
+      T t2[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float sc = rstd * gamma[g * cg + c + k];
+        float t = v[i][k] * sc + (beta[g * cg + c + k] - mu * sc);
+        if (act == ACT_SILU) t = silu_f(t);
+        t2[k] = from_f<T>(t);
+      }
+      P pv;
+      __builtin_memcpy(&pv, t2, sizeof(P));
+      *(P*)(yb + (int64_t)r * ldy + c) = pv;
+    }
+  }
+}
+
 size_t groupnorm_ws_floats(int B, int rows, int C, int groups) {
   // upper bound on B*chunks*groups*2 (chunks <= rows/16 + 1) + B*C*2
   size_t chunks = (size_t)rows / 16 + 2;
@@ -187,6 +258,14 @@ static int gn_launch(const GroupNormParams& p, hipStream_t s) {
   if (p.C % EPV != 0 || p.C > GN_MAXC || p.C % p.groups != 0 || p.groups > 256) TANGO_FAIL("groupnorm: unsupported C/groups");
   if (p.C / EPV > 256 * GN_NV) TANGO_FAIL("groupnorm: C too large");
   if ((p.ldx * (int64_t)sizeof(T)) % 16 || (p.ldy * (int64_t)sizeof(T)) % 16) TANGO_FAIL("groupnorm: ld alignment");
+  const int cg = p.C / p.groups;
+  if ((cg & 1) == 0 && (int64_t)p.rows * (cg / 2) <= (int64_t)1024 * GNS_NP && (p.ldx & 1) == 0 && (p.ldy & 1) == 0 &&
+      (size_t)p.B * p.rows * p.C * sizeof(T) <= ((size_t)8 << 20)) {
+    hipLaunchKernelGGL((gn_fused_small_kernel<T>), dim3((unsigned)p.groups, (unsigned)p.B), dim3(1024), 0, s, (const T*)p.x, p.ldx,
+                       (T*)p.y, p.ldy, p.gamma, p.beta, p.rows, p.C, p.groups, p.eps, p.act);
+    TANGO_HIP(hipGetLastError());
+    return 0;
+  }
   const GnGeom g = gn_geom<T>(p.B, p.rows, p.C);
   dim3 grid((unsigned)g.chunks, (unsigned)p.B);
   hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(256), 0, s, (const T*)p.x, p.ldx, p.partial, p.rows, p.C, p.groups,

@@ -209,7 +209,8 @@ def test_conv_transpose1d(lib, dtype, Ci, Co, L, k, u):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
-@pytest.mark.parametrize("C,HW,eps,act", [(320, 512, 1e-5, 1), (64, 4096, 1e-6, 0), (512, 100, 1e-6, 1), (2560, 64, 1e-5, 1), (1920, 33, 1e-5, 0), (128, 7000, 1e-6, 1)])
+@pytest.mark.parametrize("C,HW,eps,act", [(320, 512, 1e-5, 1), (64, 4096, 1e-6, 0), (512, 100, 1e-6, 1), (2560, 64, 1e-5, 1), (1920, 33, 1e-5, 0), (128, 7000, 1e-6, 1),
+                                              (320, 16384, 1e-5, 1), (640, 6000, 1e-5, 0)])  # last two: multi-kernel (large) path
 def test_groupnorm(lib, dtype, C, HW, eps, act):
     B = 3
     g = torch.Generator().manual_seed(C + HW)
