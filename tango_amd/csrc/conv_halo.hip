@@ -1,0 +1,282 @@
+// 3x3 / stride 1 / pad 1 convolution over channels-last activations with HALO REUSE (gfx950).
+//
+// Why: the generic implicit-GEMM kernel (gemm.hip) re-gathers the 256-pixel activation tile once per tap, i.e. 9x per
+// 128-byte channel chunk.  PMC (profiles/r1_v16_pmc_conv_l0.txt) shows that kernel waiting on LDS-DMA arrival:
+// ~13.6 B/clk/CU of global->LDS fill is the ceiling it runs into (MFMA pipes 28 % busy, 0 LDS bank conflicts, L2 hit
+// rate 92 %).
+// Here each workgroup stages the (rows+2) x (W+2) halo of its 256 output pixels ONCE per channel chunk and serves
+// all nine taps from it by shifting the fragment row index; only the 9 weight chunks stream per channel chunk.
+// Global->LDS bytes per MFMA flop drop 2.1x (activation part 5.8x).
+//
+// Structure: 512 threads = 8 waves (4 along pixels x 2 along channels), wave tile 64 x BN/2, "swapped" MFMA
+// orientation as in gemm.hip (weights = A operand).  LDS: two halo buffers (channel chunk cc and cc+1) + a 3-stage
+// ring of weight chunks, all 128-byte rows with the XOR swizzle applied on the DMA source side.  One raw s_barrier
+// per (chunk, tap) item with counted vmcnt waits; the next chunk's halo is trickled in one DMA piece per wave per
+// item.  Out-of-image halo pixels are sourced from a zero page.
+//
+// Reference op replaced: the ResnetBlock2D / VAE ResnetBlock 3x3 convolutions (diffusers/src/diffusers/models/
+// resnet.py:445-552, audioldm/variational_autoencoder/modules.py:117-176), i.e. ATen convolution.
+#include <cstdlib>
+
+#include "common.h"
+#include "gemm_device.h"
+
+namespace tango {
+
+static constexpr int HALO_MAX_ROWS = 400;   // halo pixels per tile the LDS budget allows (2 buffers)
+static constexpr int HALO_NA = 7;           // halo DMA pieces per wave per channel chunk (8 waves x 7 x 8 rows >= 400)
+
+template <typename T, int BN>
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GemmParams p, const unsigned char* zero_page, const int SR,
+                                                           const int nseg, const int abytes, const int abl, const int staged) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  constexpr int BM = 256, BKB = 128;
+  constexpr int BK = BKB / (int)sizeof(T);
+  constexpr int WST = BN * BKB;                 // bytes per weight stage
+  constexpr int WRG = BN / 8;                   // 8-row DMA groups per weight chunk
+  constexpr int WRGW = (WRG + 7) / 8;           // ... per wave (some waves own one fewer)
+  constexpr int WNR = BN / 2;
+  constexpr int TM = 4, TN = WNR / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // [halo 0 | halo 1 | W stage 0..2]
+  unsigned char* const As = dsm;
+  unsigned char* const Ws = dsm + 2 * abytes;
+
+  const int NT = p.N / BN;
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (bid / NT) * BM, n0 = (bid % NT) * BN;
+  const unsigned char* Ab = (const unsigned char*)p.A;
+  const unsigned char* Wb = (const unsigned char*)p.W;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int lrow = lane >> 3, slot = lane & 7;
+  const int pc = slot ^ lrow;
+
+  // tile geometry: 256 consecutive pixels = SR image rows of one image (nseg == 1) or nseg whole images
+  const int H = p.H, Wd = p.Wd, hw = H * Wd;
+  const int HW2 = Wd + 2, SEG = (SR + 2) * HW2;
+  const int HALO = nseg * SEG, HALO_RG = (HALO + 7) >> 3;
+  const int b0 = m0 / hw;
+  const int y0 = nseg == 1 ? (m0 - b0 * hw) / Wd : 0;
+
+  // halo DMA sources of this lane: piece t covers halo rows (t*8 + wave)*8 + lrow
+  int64_t a_src[HALO_NA];
+#pragma unroll
+  for (int t = 0; t < HALO_NA; ++t) {
+    a_src[t] = -1;
+    const int h = ((t * 8 + wave) << 3) + lrow;
+    if (h < HALO) {
+      const int seg = h / SEG, rem = h - seg * SEG;
+      const int hy = rem / HW2, hx = rem - hy * HW2;
+      const int y = y0 + hy - 1, x = hx - 1;
+      if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)Wd)
+        a_src[t] = ((((int64_t)(b0 + seg) * H + y) * Wd + x) * p.lda + pc * EPV) * (int64_t)sizeof(T);
+    }
+  }
+  // weight DMA sources
+  int64_t w_src[WRGW];
+  int my_w = 0;
+#pragma unroll
+  for (int i = 0; i < WRGW; ++i) {
+    const int rg = wave + 8 * i;
+    w_src[i] = 0;
+    if (rg < WRG) {
+      ++my_w;
+      w_src[i] = ((int64_t)(n0 + rg * 8 + lrow) * p.Kp + pc * EPV) * (int64_t)sizeof(T);
+    }
+  }
+  my_w = __builtin_amdgcn_readfirstlane(my_w);
+
+  auto issue_a = [&](const int t, const int cc, const int buf) {   // t compile-time after unrolling
+    const int ag = t * 8 + wave;
+    if (ag < HALO_RG) {
+      const unsigned char* src = a_src[t] >= 0 ? Ab + a_src[t] + (int64_t)cc * BKB : zero_page;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * abytes + ag * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_w = [&](const int tap, const int cc, const int st) {
+    const int64_t koff = ((int64_t)tap * p.Cin + (int64_t)cc * BK) * (int64_t)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < WRGW; ++i) {
+      const int rg = wave + 8 * i;
+      if (rg < WRG)
+        __builtin_amdgcn_global_load_lds((gptr_t)(Wb + w_src[i] + koff), (lptr_t)(Ws + st * WST + rg * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing
+  int h00[TM];
+#pragma unroll
+  for (int b = 0; b < TM; ++b) {
+    const int pm = wm * 64 + b * 16 + (lane & 15);
+    const int seg = pm / hw, r = pm - seg * hw;      // nseg == 1: hw >= 256 > pm -> seg = 0
+    const int ly = r / Wd, x = r - ly * Wd;
+    h00[b] = seg * SEG + ly * HW2 + x;
+  }
+  const int kg = lane >> 4;
+  int wkoff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) wkoff[ks] = (((ks * 4 + kg) ^ (lane & 7)) * 16);
+  const int wrow = (wn * WNR + (lane & 15)) * BKB;
+
+  const int NC = p.Cin / BK;
+
+  // prologue: halo of chunk 0, weight items 0 and 1
+  if (!(abl & 32)) {
+#pragma unroll
+  for (int t = 0; t < HALO_NA; ++t) issue_a(t, 0, 0);
+  issue_w(0, 0, 0);
+  issue_w(1, 0, 1);
+  }
+
+  int st = 0;   // weight stage of the current item
+  for (int cc = 0; cc < NC; ++cc) {
+    const unsigned char* Ah = As + (cc & 1) * abytes;
+    const bool more_c = cc + 1 < NC;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const bool last_item = !more_c && tap == 8;
+      // weight item (cc, tap) must have landed; item +1 (issued one item ago) may stay in flight
+      if (!last_item) {
+        if (my_w == WRGW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WRGW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WRGW - 1) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      // refill: one halo piece of the next chunk (older in the queue than the weights issued after it), then weight item +2
+      if (more_c && tap < HALO_NA && !(abl & 2)) issue_a(tap, cc + 1, (cc + 1) & 1);
+      {
+        const int t2 = tap + 2;
+        const int st2 = st == 0 ? 2 : st - 1;     // (st + 2) % 3
+        if (!(abl & 1)) {
+          if (t2 < 9) issue_w(t2, cc, st2);
+          else if (more_c) issue_w(t2 - 9, cc + 1, st2);
+        }
+      }
+      const unsigned char* Wst = Ws + st * WST;
+      const int toff = (tap / 3) * HW2 + (tap % 3);
+      // keep the 72 (tap, fragment, k-step) halo addresses out of the loop-invariant set: recomputing one costs 3 VALU,
+      // hoisting them all costs 72 VGPRs and spills the accumulators
+      int hb[TM];
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        hb[b] = h00[b];
+        asm volatile("" : "+v"(hb[b]));
+      }
+      if (!(abl & 4)) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 wf[TN], xf[TM];
+        if (!(abl & 8)) {
+#pragma unroll
+        for (int a = 0; a < TN; ++a) wf[a] = *(const u32x4*)(Wst + wrow + a * 16 * BKB + wkoff[ks]);
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+          const int h = hb[b] + toff;
+          xf[b] = *(const u32x4*)(Ah + h * BKB + (((ks * 4 + kg) ^ (h & 7)) << 4));
+        }
+        } else {
+#pragma unroll
+        for (int a = 0; a < TN; ++a) wf[a] = u32x4{(unsigned)lane, 0u, (unsigned)a, 0u};
+#pragma unroll
+        for (int b = 0; b < TM; ++b) xf[b] = u32x4{0u, (unsigned)lane, (unsigned)b, 0u};
+        }
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b) Mma<T>::run(acc[a][b], wf[a], xf[b]);
+      }
+      }
+      st = st == 2 ? 0 : st + 1;
+    }
+  }
+  if ((abl & 16) && acc[0][0][0] == 0.f) return;
+  if (staged) {
+    __syncthreads();   // every wave is past its last fragment read: the halo / weight LDS becomes the staging area
+    gemm_epilogue_staged<T, TM, TN>(p, acc, m0 + wm * 64, n0 + wn * WNR, lane, dsm + wave * (32 * (WNR * 4 + 16)));
+  } else {
+    gemm_epilogue<T, TM, TN, MODE_CONV2D>(p, acc, m0 + wm * 64, n0 + wn * WNR, lane, 0, 0);
+  }
+}
+
+struct HaloGeom {
+  int SR, nseg, halo;
+};
+
+static bool halo_geom(const GemmParams& p, HaloGeom& g) {
+  const int hw = p.H * p.Wd;
+  if (p.Wd <= 0 || 256 % p.Wd != 0) return false;
+  if (hw >= 256) {
+    if (hw % 256 != 0) return false;
+    g.SR = 256 / p.Wd; g.nseg = 1;
+  } else {
+    if (256 % hw != 0) return false;
+    g.SR = p.H; g.nseg = 256 / hw;
+  }
+  g.halo = g.nseg * (g.SR + 2) * (p.Wd + 2);
+  return g.halo <= HALO_MAX_ROWS;
+}
+
+bool conv_halo_ok(int dtype, const GemmParams& p) {
+  static const bool off = getenv("TANGO_NO_HALO_CONV") != nullptr;      // experiment switch
+  if (off) return false;
+  const int esz = dtype == DT_F32 ? 4 : 2;
+  if (p.mode != GATHER_2D || p.stride != 1 || p.ups != 0 || p.Hin != p.H || p.Win != p.Wd) return false;
+  if (p.batch != 1 || p.splitk > 1 || p.a_act != ACT_NONE || p.epi == EPI_GEGLU || p.epi == EPI_VT) return false;
+  if ((p.Cin * esz) % 128 != 0 || p.K != 9 * p.Cin || p.M % 256 != 0) return false;
+  const int bn = p.N % 160 == 0 ? 160 : 128;
+  if (p.N % bn != 0) return false;
+  HaloGeom g;
+  if (!halo_geom(p, g)) return false;
+  static const bool force = getenv("TANGO_FORCE_DMA_GEMM") != nullptr;  // tests: exercise this kernel on small shapes
+  const long tiles = (long)(p.M / 256) * (p.N / bn);
+  return force || tiles >= 256;
+}
+
+template <typename T, int BN>
+static int launch_halo_cfg(const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {
+  HaloGeom g;
+  if (!halo_geom(p, g)) TANGO_FAIL("conv_halo: unsupported geometry");
+  const int abytes = ((g.halo + 7) / 8) * 1024;
+  const int lds = 2 * abytes + 3 * BN * 128;
+  auto kfn = conv3x3_halo_kernel<T, BN>;
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_lds = lds;
+  }
+  const int tiles = (p.M / 256) * (p.N / BN);
+  static const int abl = getenv("TANGO_HALO_ABL") ? atoi(getenv("TANGO_HALO_ABL")) : 0;   // ablation study switch
+  static const bool no_stage = getenv("TANGO_NO_STAGED_EPILOGUE") != nullptr;   // experiment switch
+  const int staged = (!no_stage && epilogue_can_stage<T>(p)) ? 1 : 0;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(512), lds, s, p, zero_page, g.SR, g.nseg, abytes, abl, staged);
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_conv_halo(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {
+  if (!zero_page) TANGO_FAIL("conv_halo: gemm_init() was not called (zero page for the LDS-DMA gather)");
+  const bool bn160 = p.N % 160 == 0;
+  switch (dtype) {
+    case DT_F32: return bn160 ? launch_halo_cfg<float, 160>(p, zero_page, s) : launch_halo_cfg<float, 128>(p, zero_page, s);
+    case DT_F16: return bn160 ? launch_halo_cfg<f16, 160>(p, zero_page, s) : launch_halo_cfg<f16, 128>(p, zero_page, s);
+    case DT_BF16: return bn160 ? launch_halo_cfg<bf16, 160>(p, zero_page, s) : launch_halo_cfg<bf16, 128>(p, zero_page, s);
+  }
+  TANGO_FAIL("conv_halo: bad dtype");
+}
+
+}  // namespace tango

@@ -16,185 +16,10 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "gemm_device.h"
 
 namespace tango {
 
-template <typename T> struct Mma;
-template <> struct Mma<float> {
-  __device__ static __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
-    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc, 0, 0, 0);
-  }
-};
-template <> struct Mma<f16> {
-  __device__ static __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
-  }
-};
-template <> struct Mma<bf16> {
-  __device__ static __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-  }
-};
-
-template <typename T> __device__ __forceinline__ u32x4 act_vec(u32x4 v, int act, float slope) {
-  constexpr int EPV = 16 / sizeof(T);
-  T e[EPV];
-  __builtin_memcpy(e, &v, 16);
-#pragma unroll
-  for (int i = 0; i < EPV; ++i) e[i] = from_f<T>(apply_act(to_f(e[i]), act, slope));
-  __builtin_memcpy(&v, e, 16);
-  return v;
-}
-
-enum : int { MODE_LINEAR = 0, MODE_CONV2D = 1, MODE_CONV1D = 2 };
-
-// Shared epilogue of the GEMM kernels: acc[a][b] is the 16x16 tile at rows m_base + b*16.., cols n_base + a*16..
-// (A paired-tile variant with 16-byte residual loads/stores was measured in round 1: correct, not faster -- the
-// cross-lane exchange costs what the wider accesses save.  Note for future work: cross-lane intrinsics are
-// `convergent`; LLVM refuses to fully unroll loops containing them and the accumulator array then lands in scratch.)
-template <typename T, int TM, int TN, int MODE>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[TN][TM], const int m_base, const int n_base,
-                                              const int lane, const int zb, const int split) {
-  // ---------------- epilogue ----------------
-  const int g4 = (lane >> 4) * 4;
-  if (p.splitk > 1) {   // raw fp32 partial tile -> workspace; the reduce kernel finishes the job
-    float* wsb = p.ws + (int64_t)split * p.M * p.N;
-#pragma unroll
-    for (int b = 0; b < TM; ++b) {
-      const int m = m_base + b * 16 + (lane & 15);
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int a = 0; a < TN; ++a) {
-        const int n = n_base + a * 16 + g4;
-        if (n + 3 < p.N) *(f32x4*)(wsb + (int64_t)m * p.N + n) = acc[a][b];
-        else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (n + r < p.N) wsb[(int64_t)m * p.N + n + r] = acc[a][b][r];
-        }
-      }
-    }
-    return;
-  }
-  const float* bias = p.bias ? p.bias + (int64_t)zb * p.sBias : nullptr;
-  const float* bias2 = nullptr;
-  if (p.bias2) bias2 = p.bias2 + (int64_t)(p.step_ptr ? *p.step_ptr : 0) * p.bias2_stride;
-  unsigned char* Ob = (unsigned char*)p.out;
-  const unsigned char* Rb = (const unsigned char*)p.R;
-  const int osz = p.epi == EPI_I16 ? 2 : (p.out_f32 ? 4 : (int)sizeof(T));
-  Ob += (int64_t)zb * p.sO * osz;
-  if (Rb) Rb += (int64_t)zb * p.sR * (int64_t)sizeof(T);
-
-  int64_t orow[TM], vtrow[TM];
-#pragma unroll
-  for (int b = 0; b < TM; ++b) {
-    const int m = m_base + b * 16 + (lane & 15);
-    orow[b] = -1; vtrow[b] = 0;
-    if (m < p.M) {
-      if (p.epi == EPI_VT) {
-        const int bb = m / p.vt_S;
-        vtrow[b] = (int64_t)bb * (p.N - p.vt_n0) * p.vt_ld + (m - bb * p.vt_S);
-      }
-      if (MODE == MODE_CONV1D) {
-        const int bb = m / p.rows_pb, q = m - bb * p.rows_pb;
-        orow[b] = (int64_t)bb * p.Lout + (int64_t)q * p.out_mul + p.out_off;
-      } else {
-        orow[b] = m;
-      }
-    }
-  }
-
-#pragma unroll
-  for (int a = 0; a < TN; ++a) {
-    if (p.epi == EPI_GEGLU && (a & 1)) continue;
-    const int nt = n_base + a * 16;   // tile base column (packed order)
-    const int n = nt + g4;
-    if (n >= p.N) continue;
-    // per-column constants of this lane's 4 output channels
-    float cb[4] = {0.f, 0.f, 0.f, 0.f}, cg[4] = {0.f, 0.f, 0.f, 0.f};
-    if (!p.bias_rows) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (n + r < p.N) {
-          if (bias) cb[r] = bias[n + r];
-          if (bias2) cb[r] += bias2[n + r];
-          if (p.epi == EPI_GEGLU && bias) cg[r] = bias[n + 16 + r];
-        }
-      }
-    }
-    int oc = n, ncols = p.N;
-    if (p.epi == EPI_GEGLU) { oc = (nt >> 1) + g4; ncols = p.N >> 1; }
-    const bool to_vt = (p.epi == EPI_VT) && n >= p.vt_n0;
-    if (p.epi == EPI_VT) ncols = p.vt_n0;
-    const bool full = (oc + 3 < ncols);
-#pragma unroll
-    for (int b = 0; b < TM; ++b) {
-      if (orow[b] < 0) continue;
-      float v[4];
-      const float rb = (bias && p.bias_rows) ? bias[orow[b]] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha + cb[r] + rb;
-      if (p.epi == EPI_GEGLU) {
-        // packed rows: [16 value | 16 gate] blocks -> out col = nt/2 + g4 + r
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float gt = acc[a + 1 < TN ? a + 1 : a][b][r] * p.alpha + cg[r];
-          v[r] = v[r] * gelu_erf_f(gt);
-        }
-      } else if (p.e_act != ACT_NONE) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.e_act, p.e_slope);
-      }
-      if (Rb) {
-        const T* rp = (const T*)Rb + orow[b] * p.ldr + oc;
-        if (full && ((p.ldr | oc) & 3) == 0) {
-          T rv[4];
-          __builtin_memcpy(rv, rp, 4 * sizeof(T));
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += to_f(rv[r]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (oc + r < ncols) v[r] += to_f(rp[r]);
-        }
-      }
-      if (p.out_scale != 1.f) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= p.out_scale;
-      }
-      if (to_vt) {
-        T* vp = (T*)p.vt + vtrow[b] + (int64_t)(n - p.vt_n0) * p.vt_ld;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (n + r < p.N) vp[(int64_t)r * p.vt_ld] = from_f<T>(v[r]);
-      } else if (p.epi == EPI_I16) {
-        int16_t* op = (int16_t*)Ob + orow[b] * p.ldo + oc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (oc + r < ncols) op[r] = (int16_t)(int)v[r];   // C truncation, int16 wrap (hifigan/utilities.py:81)
-      } else if (p.out_f32) {
-        float* op = (float*)Ob + orow[b] * p.ldo + oc;
-        if (full && ((p.ldo | oc) & 3) == 0) {
-          *(f32x4*)op = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (oc + r < ncols) op[r] = v[r];
-        }
-      } else {
-        T* op = (T*)Ob + orow[b] * p.ldo + oc;
-        T tv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tv[r] = from_f<T>(v[r]);
-        if (full && ((p.ldo | oc) & 3) == 0) {
-          __builtin_memcpy(op, tv, 4 * sizeof(T));
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (oc + r < ncols) op[r] = tv[r];
-        }
-      }
-    }
-  }
-}
 
 template <typename T, int BM, int BN, int BKB, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256, (BKB == 64 ? 3 : 2)) void gemm_kernel(const GemmParams p) {
@@ -384,11 +209,8 @@ __global__ __launch_bounds__(256, (BKB == 64 ? 3 : 2)) void gemm_kernel(const Ge
 // row r receives global piece s ^ (r & 7); fragment reads use the same involution.  Padding / out-of-range
 // rows are sourced from a zero page.
 // ------------------------------------------------------------------------------------------------
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
 template <typename T, int BN, int MODE>
-__global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GemmParams p, const unsigned char* zero_page) {
+__global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GemmParams p, const unsigned char* zero_page, const int staged) {
   constexpr int EPV = 16 / (int)sizeof(T);
   constexpr int BM = 256, BKB = 128;
   constexpr int BK = BKB / (int)sizeof(T);
@@ -533,7 +355,12 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GemmParams p, co
     }
     st = st == 2 ? 0 : st + 1;
   }
-  gemm_epilogue<T, TM, TN, MODE>(p, acc, m0 + wm * WMR, n0 + wn * WNR, lane, 0, 0);
+  if (MODE != MODE_CONV1D && staged) {
+    __syncthreads();   // every wave is past its last fragment read: the operand stages become the staging area
+    gemm_epilogue_staged<T, TM, TN>(p, acc, m0 + wm * WMR, n0 + wn * WNR, lane, dsm + wave * (32 * (WNR * 4 + 16)));
+  } else {
+    gemm_epilogue<T, TM, TN, MODE>(p, acc, m0 + wm * WMR, n0 + wn * WNR, lane, 0, 0);
+  }
 }
 
 // sums the split-K partials in split order and applies the epilogue (bias, per-step bias, activation, residual)
@@ -636,7 +463,9 @@ static int launch_dma_cfg(const GemmParams& p, hipStream_t s) {
     attr_set = true;
   }
   const int MT = (p.M + 255) / 256, NT = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)(MT * NT)), dim3(512), LDS, s, p, (const unsigned char*)g_zero_page);
+  static const bool no_stage = getenv("TANGO_NO_STAGED_EPILOGUE") != nullptr;   // experiment switch
+  const int staged = (!no_stage && MODE != MODE_CONV1D && epilogue_can_stage<T>(p)) ? 1 : 0;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)(MT * NT)), dim3(512), LDS, s, p, (const unsigned char*)g_zero_page, staged);
   TANGO_HIP(hipGetLastError());
   return 0;
 }
@@ -699,6 +528,7 @@ int gemm_pick_splitk(int dtype, const GemmParams& p) {
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
   if (linear_stream_ok(dtype, p)) return launch_linear_stream(dtype, p, s);
   if (p.ln_fold) TANGO_FAIL("gemm: ln_fold is only implemented by the streaming linear kernel");
+  if (conv_halo_ok(dtype, p)) return launch_conv_halo(dtype, p, g_zero_page, s);
   if (gemm_dma_ok(dtype, p)) {
     switch (dtype) {
       case DT_F32: return launch_dma<float>(p, s);

@@ -1,0 +1,286 @@
+// Device-side pieces shared by the MFMA GEMM kernels (gemm.hip, conv_halo.hip): MFMA wrappers, the activation helper
+// and the common epilogue (bias / per-step bias / activation / residual / GEGLU / V^T / int16 / split-K partials).
+#pragma once
+#include <cstdint>
+
+#include "common.h"
+
+namespace tango {
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+  __device__ static __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<f16> {
+  __device__ static __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<bf16> {
+  __device__ static __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  }
+};
+
+template <typename T> __device__ __forceinline__ u32x4 act_vec(u32x4 v, int act, float slope) {
+  constexpr int EPV = 16 / sizeof(T);
+  T e[EPV];
+  __builtin_memcpy(e, &v, 16);
+#pragma unroll
+  for (int i = 0; i < EPV; ++i) e[i] = from_f<T>(apply_act(to_f(e[i]), act, slope));
+  __builtin_memcpy(&v, e, 16);
+  return v;
+}
+
+enum : int { MODE_LINEAR = 0, MODE_CONV2D = 1, MODE_CONV1D = 2 };
+
+// Shared epilogue of the GEMM kernels: acc[a][b] is the 16x16 tile at rows m_base + b*16.., cols n_base + a*16..
+// (A paired-tile variant with 16-byte residual loads/stores was measured in round 1: correct, not faster -- the
+// cross-lane exchange costs what the wider accesses save.  Note for future work: cross-lane intrinsics are
+// `convergent`; LLVM refuses to fully unroll loops containing them and the accumulator array then lands in scratch.)
+template <typename T, int TM, int TN, int MODE>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[TN][TM], const int m_base, const int n_base,
+                                              const int lane, const int zb, const int split) {
+  // ---------------- epilogue ----------------
+  const int g4 = (lane >> 4) * 4;
+  if (p.splitk > 1) {   // raw fp32 partial tile -> workspace; the reduce kernel finishes the job
+    float* wsb = p.ws + (int64_t)split * p.M * p.N;
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      const int m = m_base + b * 16 + (lane & 15);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int a = 0; a < TN; ++a) {
+        const int n = n_base + a * 16 + g4;
+        if (n + 3 < p.N) *(f32x4*)(wsb + (int64_t)m * p.N + n) = acc[a][b];
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n + r < p.N) wsb[(int64_t)m * p.N + n + r] = acc[a][b][r];
+        }
+      }
+    }
+    return;
+  }
+  const float* bias = p.bias ? p.bias + (int64_t)zb * p.sBias : nullptr;
+  const float* bias2 = nullptr;
+  if (p.bias2) bias2 = p.bias2 + (int64_t)(p.step_ptr ? *p.step_ptr : 0) * p.bias2_stride;
+  unsigned char* Ob = (unsigned char*)p.out;
+  const unsigned char* Rb = (const unsigned char*)p.R;
+  const int osz = p.epi == EPI_I16 ? 2 : (p.out_f32 ? 4 : (int)sizeof(T));
+  Ob += (int64_t)zb * p.sO * osz;
+  if (Rb) Rb += (int64_t)zb * p.sR * (int64_t)sizeof(T);
+
+  int64_t orow[TM], vtrow[TM];
+#pragma unroll
+  for (int b = 0; b < TM; ++b) {
+    const int m = m_base + b * 16 + (lane & 15);
+    orow[b] = -1; vtrow[b] = 0;
+    if (m < p.M) {
+      if (p.epi == EPI_VT) {
+        const int bb = m / p.vt_S;
+        vtrow[b] = (int64_t)bb * (p.N - p.vt_n0) * p.vt_ld + (m - bb * p.vt_S);
+      }
+      if (MODE == MODE_CONV1D) {
+        const int bb = m / p.rows_pb, q = m - bb * p.rows_pb;
+        orow[b] = (int64_t)bb * p.Lout + (int64_t)q * p.out_mul + p.out_off;
+      } else {
+        orow[b] = m;
+      }
+    }
+  }
+
+#pragma unroll
+  for (int a = 0; a < TN; ++a) {
+    if (p.epi == EPI_GEGLU && (a & 1)) continue;
+    const int nt = n_base + a * 16;   // tile base column (packed order)
+    const int n = nt + g4;
+    if (n >= p.N) continue;
+    // per-column constants of this lane's 4 output channels
+    float cb[4] = {0.f, 0.f, 0.f, 0.f}, cg[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!p.bias_rows) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (n + r < p.N) {
+          if (bias) cb[r] = bias[n + r];
+          if (bias2) cb[r] += bias2[n + r];
+          if (p.epi == EPI_GEGLU && bias) cg[r] = bias[n + 16 + r];
+        }
+      }
+    }
+    int oc = n, ncols = p.N;
+    if (p.epi == EPI_GEGLU) { oc = (nt >> 1) + g4; ncols = p.N >> 1; }
+    const bool to_vt = (p.epi == EPI_VT) && n >= p.vt_n0;
+    if (p.epi == EPI_VT) ncols = p.vt_n0;
+    const bool full = (oc + 3 < ncols);
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      if (orow[b] < 0) continue;
+      float v[4];
+      const float rb = (bias && p.bias_rows) ? bias[orow[b]] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha + cb[r] + rb;
+      if (p.epi == EPI_GEGLU) {
+        // packed rows: [16 value | 16 gate] blocks -> out col = nt/2 + g4 + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gt = acc[a + 1 < TN ? a + 1 : a][b][r] * p.alpha + cg[r];
+          v[r] = v[r] * gelu_erf_f(gt);
+        }
+      } else if (p.e_act != ACT_NONE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.e_act, p.e_slope);
+      }
+      if (Rb) {
+        const T* rp = (const T*)Rb + orow[b] * p.ldr + oc;
+        if (full && ((p.ldr | oc) & 3) == 0) {
+          T rv[4];
+          __builtin_memcpy(rv, rp, 4 * sizeof(T));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += to_f(rv[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (oc + r < ncols) v[r] += to_f(rp[r]);
+        }
+      }
+      if (p.out_scale != 1.f) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= p.out_scale;
+      }
+      if (to_vt) {
+        T* vp = (T*)p.vt + vtrow[b] + (int64_t)(n - p.vt_n0) * p.vt_ld;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n + r < p.N) vp[(int64_t)r * p.vt_ld] = from_f<T>(v[r]);
+      } else if (p.epi == EPI_I16) {
+        int16_t* op = (int16_t*)Ob + orow[b] * p.ldo + oc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (oc + r < ncols) op[r] = (int16_t)(int)v[r];   // C truncation, int16 wrap (hifigan/utilities.py:81)
+      } else if (p.out_f32) {
+        float* op = (float*)Ob + orow[b] * p.ldo + oc;
+        if (full && ((p.ldo | oc) & 3) == 0) {
+          *(f32x4*)op = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (oc + r < ncols) op[r] = v[r];
+        }
+      } else {
+        T* op = (T*)Ob + orow[b] * p.ldo + oc;
+        T tv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tv[r] = from_f<T>(v[r]);
+        if (full && ((p.ldo | oc) & 3) == 0) {
+          __builtin_memcpy(op, tv, 4 * sizeof(T));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (oc + r < ncols) op[r] = tv[r];
+        }
+      }
+    }
+  }
+}
+
+// LDS-staged epilogue for the 8-wave kernels (plain outputs: EPI_NONE, storage dtype T).
+// The direct epilogue above stores 8 bytes per lane = 32-byte runs per output row; measured on the level-0 conv
+// (ablation in profiles/r1_v16_conv_halo_ablation.txt) those partial-line writes cost 175 us of a 660 us kernel.
+// Here each wave parks 32 rows x (TN*16) fp32 results in its private LDS region (bias / per-step bias / activation
+// already applied, same fp32 arithmetic and order as the direct path -> bit-identical results), then walks the rows
+// with 16-byte pieces: residual read, add, scale, convert, 16-byte store -> TN*16*sizeof(T)-byte contiguous runs.
+// Caller guarantees: all waves are past their last LDS read (barrier), p.epi == EPI_NONE, !p.out_f32, n_base + TN*16 <= N,
+// ldo / ldr multiples of 16/sizeof(T), 16-byte aligned out / R.
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4 (&acc)[TN][TM], const int m_base, const int n_base,
+                                                     const int lane, unsigned char* stage) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  constexpr int WN = TN * 16;
+  constexpr int PITCH = WN * 4 + 16;       // bytes per staged row (+16: spreads rows over the banks)
+  constexpr int PPR = WN / EPV;            // 16-byte output pieces per row
+  static_assert((32 * PPR) % 64 == 0, "staged epilogue: 32 rows must split into whole wave passes");
+  const int g4 = (lane >> 4) * 4;
+  const float* bias = p.bias;
+  const float* bias2 = p.bias2 ? p.bias2 + (int64_t)(p.step_ptr ? *p.step_ptr : 0) * p.bias2_stride : nullptr;
+  float cb[TN][4];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n_base + a * 16 + g4 + r;
+      float c = 0.f;
+      if (!p.bias_rows && bias) c = bias[n];
+      if (!p.bias_rows && bias2) c += bias2[n];
+      cb[a][r] = c;
+    }
+  const T* Rb = (const T*)p.R;
+  T* Ob = (T*)p.out;
+#pragma unroll
+  for (int half = 0; half < TM / 2; ++half) {
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      const int b = half * 2 + bb;
+      const int row_l = bb * 16 + (lane & 15);
+      const int m = m_base + b * 16 + (lane & 15);
+      const float rb = (bias && p.bias_rows && m < p.M) ? bias[m] : 0.f;
+#pragma unroll
+      for (int a = 0; a < TN; ++a) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha + cb[a][r] + rb;
+        if (p.e_act != ACT_NONE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.e_act, p.e_slope);
+        }
+        *(f32x4*)(stage + row_l * PITCH + (a * 16 + g4) * 4) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < (32 * PPR) / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int row_l = idx / PPR, pcs = idx - row_l * PPR;
+      const int m = m_base + half * 32 + row_l;
+      if (m < p.M) {
+        float f[EPV];
+#pragma unroll
+        for (int q = 0; q < EPV / 4; ++q) {
+          const f32x4 t = *(const f32x4*)(stage + row_l * PITCH + (pcs * EPV + q * 4) * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) f[q * 4 + r] = t[r];
+        }
+        const int n = n_base + pcs * EPV;
+        if (Rb) {
+          T rv[EPV];
+          __builtin_memcpy(rv, Rb + (int64_t)m * p.ldr + n, 16);
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) f[e] += to_f(rv[e]);
+        }
+        if (p.out_scale != 1.f) {
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) f[e] *= p.out_scale;
+        }
+        T tv[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) tv[e] = from_f<T>(f[e]);
+        __builtin_memcpy(Ob + (int64_t)m * p.ldo + n, tv, 16);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// host-side predicate for the staged epilogue
+template <typename T> static inline bool epilogue_can_stage(const GemmParams& p) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  if (p.epi != EPI_NONE || p.out_f32 || p.splitk > 1 || p.batch != 1) return false;
+  if (p.ldo % EPV != 0 || ((uintptr_t)p.out & 15)) return false;
+  if (p.R && (p.ldr % EPV != 0 || ((uintptr_t)p.R & 15))) return false;
+  return true;
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+}  // namespace tango

@@ -176,6 +176,23 @@ def test_conv2d(lib, dtype, Cin, Cout, H, W, stride, ups):
     close(out, ref, dtype, "conv2d")
 
 
+# Halo-reuse 3x3 conv (conv_halo.hip): tile counts >= 256 select it without any env switch.  Geometries: 16-wide rows
+# (UNet level 0), 8- and 4-wide (levels 1, 2: fragments straddle image rows), 64-wide (VAE), whole-image segments
+# (8x8 images, 4 per tile: the 400-row LDS maximum), BN = 160 and 128, several channel chunks.
+@pytest.mark.parametrize("dtype", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(16, 64, 640, 64, 16), (32, 128, 640, 64, 8), (64, 192, 640, 64, 4),
+                                            (32, 64, 512, 8, 64), (256, 64, 512, 8, 8), (2, 64, 1280, 256, 16)])
+def test_conv2d_halo(lib, dtype, B, Cin, Cout, H, W):
+    g = torch.Generator().manual_seed(Cin * Cout + H + W)
+    x = quant(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = quant(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5, dtype)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b, padding=1)
+    out = torch.empty(ref.shape, device="cuda")
+    check(lib, lib.tango_op_conv2d(DT[dtype], ptr(dev(x)), ptr(dev(w)), ptr(dev(b)), ptr(out), B, Cin, H, W, Cout, 1, 0, None))
+    close(out, ref, dtype, "conv2d halo")
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
 @pytest.mark.parametrize("C,Co,L,k,d", [(32, 32, 301, 3, 1), (32, 32, 301, 7, 3), (64, 64, 200, 11, 5), (64, 128, 77, 7, 1), (32, 1, 500, 7, 1)])
 def test_conv1d(lib, dtype, C, Co, L, k, d):
