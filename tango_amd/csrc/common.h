@@ -99,6 +99,7 @@ struct GemmParams {
   int M = 0, N = 0, K = 0, Cin = 0;
   int64_t Kp = 0;            // W row stride
   int64_t lda = 0;
+  int stage_epi = 0;           // set by the launchers: LDS-staged (row-contiguous) output stores
   int mode = GATHER_1D;
   // 2D: output grid H x W per image; source image Hin x Win (conv input is source upsampled if ups)
   int H = 0, Wd = 0, Hin = 0, Win = 0, stride = 1, ups = 0;

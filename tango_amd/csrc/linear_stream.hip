@@ -12,6 +12,8 @@
 //     (BasicTransformerBlock norm1/2/3, mustango/diffusers/src/diffusers/models/attention.py:276-335).
 #include <cstdlib>
 
+#include <cstdint>
+
 #include "common.h"
 
 namespace tango {
@@ -77,6 +79,13 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
       *(u32x4*)(wlds + row * ROWB + seg * 128 + ((pp ^ (row & 7)) * 16)) = v;
     }
   }
+  {   // per-column epilogue constants of this panel: [bias | wsum] (fp32), read back through lgkmcnt, not vmcnt
+    float* cstw = (float*)(wlds + BN * ROWB + 8 * 16 * (BN * (int)sizeof(T) + 16));
+    for (int i = tid; i < BN; i += 512) {
+      cstw[i] = p.bias ? p.bias[n0 + i] : 0.f;
+      cstw[BN + i] = p.ln_fold ? p.wsum[n0 + i] : 0.f;
+    }
+  }
   __syncthreads();
 
   // ---- this workgroup's rows: groups of 32 rows, dealt round-robin to the 8 waves ----
@@ -128,7 +137,6 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
 #pragma unroll
       for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     float ssum[TM] = {0.f, 0.f}, ssq[TM] = {0.f, 0.f};
-
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int ks = u / NH, hh = u % NH;
@@ -172,60 +180,100 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
         mean[tm] = mu; rstd[tm] = rsqrtf(var + p.ln_eps);
       }
     }
+    // The epilogue must not contain dependent global-load chains: vmcnt is in-order, so every load -> use here also
+    // waits for the next group's prefetched activation rows, and each extra round trip is exposed (2 waves/SIMD).
+    // Per-column constants therefore come from LDS (lgkmcnt), the residual quads are fetched in ONE batch up front,
+    // and rows beyond M are clamped (loads) / masked (stores) instead of branched around.
+    // (n0e / g4e are made opaque per group: otherwise every per-column address below is hoisted out of the group loop
+    //  as a loop invariant -- ~30 64-bit values -- and spilled, and scratch reloads are vmcnt traffic too)
+    int n0e = n0, g4e = g4;
+    asm volatile("" : "+s"(n0e));
+    asm volatile("" : "+v"(g4e));
     int64_t orow[TM], vtrow[TM];
+    bool rok[TM];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int m = grp * 32 + tm * 16 + l15;
-      orow[tm] = m < p.M ? m : -1; vtrow[tm] = 0;
-      if (p.epi == EPI_VT && m < p.M) {
-        const int bb = m / p.vt_S;
-        vtrow[tm] = (int64_t)bb * (p.N - p.vt_n0) * p.vt_ld + (m - bb * p.vt_S);
+      rok[tm] = m < p.M;
+      orow[tm] = rok[tm] ? m : p.M - 1; vtrow[tm] = 0;
+      if (p.epi == EPI_VT) {
+        const int mm = (int)orow[tm];
+        const int bb = mm / p.vt_S;
+        vtrow[tm] = (int64_t)bb * (p.N - p.vt_n0) * p.vt_ld + (mm - bb * p.vt_S);
       }
     }
+    const bool panel_vt = (p.epi == EPI_VT) && n0e >= p.vt_n0;
+    const bool stage = p.stage_epi && !panel_vt && !(p.epi == EPI_VT && n0e + BN > p.vt_n0);
+    constexpr int SPITCH = BN * (int)sizeof(T) + 16;
+    unsigned char* const stg = wlds + BN * ROWB + wave * (16 * SPITCH);
+    const float* const cst = (const float*)(wlds + BN * ROWB + 8 * 16 * SPITCH);   // [bias BN | wsum BN]
+
+    T rv[TM][TN][4];
+    if (p.R) {
 #pragma unroll
-    for (int a = 0; a < TN; ++a) {
-      if (p.epi == EPI_GEGLU && (a & 1)) continue;
-      const int nt = n0 + a * 16;
-      const int n = nt + g4;
-      float cb[4], cw[4], gb[4] = {0.f, 0.f, 0.f, 0.f}, gw[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        cb[r] = bias ? bias[n + r] : 0.f;
-        cw[r] = p.ln_fold ? p.wsum[n + r] : 0.f;
-        if (p.epi == EPI_GEGLU) { gb[r] = bias ? bias[n + 16 + r] : 0.f; gw[r] = p.ln_fold ? p.wsum[n + 16 + r] : 0.f; }
-      }
-      int oc = n;
-      if (p.epi == EPI_GEGLU) oc = (nt >> 1) + g4;
-      const bool to_vt = (p.epi == EPI_VT) && n >= p.vt_n0;
+        for (int a = 0; a < TN; ++a)
+          __builtin_memcpy(rv[tm][a], (const T*)p.R + orow[tm] * p.ldr + n0e + a * 16 + g4e, 4 * sizeof(T));
+    }
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        if (orow[tm] < 0) continue;
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int a = 0; a < TN; ++a) {
+        if (p.epi == EPI_GEGLU && (a & 1)) continue;
+        const int nt = n0e + a * 16;
+        const int n = nt + g4e;
+        const f32x4 cb = *(const f32x4*)(cst + a * 16 + g4e);
+        const f32x4 cw = *(const f32x4*)(cst + BN + a * 16 + g4e);
+        int oc = n, ocl = a * 16 + g4e;                  // output column (global / within the staged slice)
+        if (p.epi == EPI_GEGLU) { oc = (nt >> 1) + g4e; ocl = (a >> 1) * 16 + g4e; }
+        const bool to_vt = (p.epi == EPI_VT) && n >= p.vt_n0;
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = rstd[tm] * (acc[a][tm][r] - mean[tm] * cw[r]) + cb[r];
         if (p.epi == EPI_GEGLU) {
+          const int a1 = a + 1 < TN ? a + 1 : a;
+          const f32x4 gb = *(const f32x4*)(cst + a1 * 16 + g4e);
+          const f32x4 gw = *(const f32x4*)(cst + BN + a1 * 16 + g4e);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float gt = rstd[tm] * (acc[a + 1 < TN ? a + 1 : a][tm][r] - mean[tm] * gw[r]) + gb[r];
+            const float gt = rstd[tm] * (acc[a1][tm][r] - mean[tm] * gw[r]) + gb[r];
             v[r] = v[r] * gelu_erf_f(gt);
           }
         }
         if (p.R) {
-          T rv[4];
-          __builtin_memcpy(rv, (const T*)p.R + orow[tm] * p.ldr + oc, 4 * sizeof(T));
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += to_f(rv[r]);
+          for (int r = 0; r < 4; ++r) v[r] += to_f(rv[tm][a][r]);
         }
         T tv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) tv[r] = from_f<T>(v[r]);
-        if (to_vt) {
-          T* vp = (T*)p.vt + vtrow[tm] + (int64_t)(n - p.vt_n0) * p.vt_ld;
+        if (stage) {
+          __builtin_memcpy(stg + l15 * SPITCH + ocl * (int)sizeof(T), tv, 4 * sizeof(T));
+        } else if (to_vt) {
+          if (rok[tm]) {
+            T* vp = (T*)p.vt + vtrow[tm] + (int64_t)(n - p.vt_n0) * p.vt_ld;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) vp[(int64_t)r * p.vt_ld] = tv[r];
+            for (int r = 0; r < 4; ++r) vp[(int64_t)r * p.vt_ld] = tv[r];
+          }
         } else {
-          __builtin_memcpy((T*)p.out + orow[tm] * p.ldo + oc, tv, 4 * sizeof(T));
+          if (rok[tm]) __builtin_memcpy((T*)p.out + orow[tm] * p.ldo + oc, tv, 4 * sizeof(T));
         }
+      }
+      if (stage) {
+        __builtin_amdgcn_wave_barrier();
+        constexpr int EPV = 16 / (int)sizeof(T);
+        const int ppr = (p.epi == EPI_GEGLU ? BN / 2 : BN) / EPV;           // 16-byte pieces per output row
+        const int ocol0 = p.epi == EPI_GEGLU ? (n0e >> 1) : n0e;
+        for (int idx = lane; idx < 16 * ppr; idx += 64) {
+          const int row_l = idx / ppr, pcs = idx - row_l * ppr;
+          const int m = grp * 32 + tm * 16 + row_l;
+          if (m < p.M) {
+            const u32x4 t = *(const u32x4*)(stg + row_l * SPITCH + pcs * 16);
+            *(u32x4*)((T*)p.out + (int64_t)m * p.ldo + ocol0 + pcs * EPV) = t;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
       }
     }
   }
@@ -234,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
 template <typename T, int KS, int TN>
 static int stream_launch(const GemmParams& p, hipStream_t s) {
   constexpr int BN = TN * 16;
-  constexpr int LDS = BN * KS * 64;
+  constexpr int LDS = BN * KS * 64 + 8 * 16 * (BN * (int)sizeof(T) + 16) + 2 * BN * 4;   // weight panel + per-wave output staging + constants
   static bool attr_set = false;
   auto kfn = lin_stream_kernel<T, KS, TN>;
   if (!attr_set) {
@@ -246,7 +294,11 @@ static int stream_launch(const GemmParams& p, hipStream_t s) {
   if (rpx < 1) rpx = 1;
   const int ngroups = (p.M + 31) / 32;
   while (rpx > 1 && 8 * rpx * 8 > ngroups) --rpx;   // keep >= 8 row groups (one per wave) per workgroup
-  hipLaunchKernelGGL(kfn, dim3((unsigned)(8 * NP * rpx)), dim3(512), LDS, s, p);
+  static const bool no_stage = getenv("TANGO_NO_STAGED_EPILOGUE") != nullptr;   // experiment switch
+  GemmParams q = p;
+  constexpr int EPVH = 16 / (int)sizeof(T);
+  q.stage_epi = (!no_stage && p.ldo % EPVH == 0 && ((uintptr_t)p.out & 15) == 0 && (p.epi != EPI_GEGLU || (BN / 2) % EPVH == 0)) ? 1 : 0;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)(8 * NP * rpx)), dim3(512), LDS, s, q);
   TANGO_HIP(hipGetLastError());
   return 0;
 }
