@@ -15,6 +15,8 @@
 // ds_read_b128), two stages, ONE barrier per 64-key tile.  For 16-bit types the V^T tile columns are
 // stored in the order the P^T accumulator fragments present them ([4g..4g+3 | 16+4g..16+4g+3] adjacent),
 // so each PV fragment is a single ds_read_b128.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace tango {
@@ -40,8 +42,11 @@ template <> struct AMma<bf16> {
   }
 };
 
-template <typename T, int QB, bool MASKED>
-__global__ __launch_bounds__(256, 3) void attn_kernel(const AttnParams p) {
+// NW waves per workgroup share one K / V^T tile stream: the L2 -> LDS fill per workgroup is fixed (the whole K and V of
+// the (batch, head)), so the fill bytes per MFMA flop scale with 1 / (NW * QB).
+template <typename T, int QB, bool MASKED, int NW, int MINW>
+__global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p) {
+  constexpr int NTH = NW * 64;
   constexpr int EPV = 16 / (int)sizeof(T);
   constexpr int D = 64, KVT = 64;
   constexpr bool HALF = sizeof(T) == 2;
@@ -49,7 +54,8 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const AttnParams p) {
   constexpr int LDSR = HALF ? ROWB : ROWB + 16;     // 128-byte rows are XOR-swizzled, 256-byte rows padded
   constexpr int NKG = ROWB / 64;                    // 64-byte k groups over head_dim
   constexpr int PPR = ROWB / 16;
-  constexpr int NPASS = KVT * PPR / 256;
+  constexpr int NPIECE = KVT * PPR;
+  constexpr int NPASS = (NPIECE + NTH - 1) / NTH;
   constexpr int STAGE = 2 * KVT * LDSR;
   constexpr float LOG2E = 1.4426950408889634f;
 
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int qbase = blockIdx.x * (64 * QB) + wave * (16 * QB);
+  const int qbase = blockIdx.x * (NW * 16 * QB) + wave * (16 * QB);
 
   const T* Qp = (const T*)p.q + (int64_t)b * p.Sq * p.ldq + h * D;
   const T* Kp = (const T*)p.k + (int64_t)b * p.Skv * p.ldk + h * D;
@@ -93,9 +99,10 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const AttnParams p) {
   auto load_tile = [&](int kv0) {
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
-      const int id = tid + i * 256;
+      const int id = tid + i * NTH;
       const int row = id / PPR, pc = id % PPR;
       u32x4 kk = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
+      if (NPIECE % NTH != 0 && id >= NPIECE) continue;
       if (kv0 + row < p.Skv) kk = *(const u32x4*)((const unsigned char*)(Kp + (int64_t)(kv0 + row) * p.ldk) + pc * 16);
       if (kv0 + pc * EPV < p.ldvt) vv = *(const u32x4*)((const unsigned char*)(Vp + (int64_t)row * p.ldvt + kv0) + pc * 16);
       kreg[i] = kk; vreg[i] = vv;
@@ -106,8 +113,9 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const AttnParams p) {
     unsigned char* Vs = Ks + KVT * LDSR;
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
-      const int id = tid + i * 256;
+      const int id = tid + i * NTH;
       const int row = id / PPR, pc = id % PPR;
+      if (NPIECE % NTH != 0 && id >= NPIECE) continue;
       if (HALF) {
         *(u32x4*)(Ks + row * LDSR + ((pc ^ (row & 7)) * 16)) = kreg[i];
         // V^T: piece pc holds kv = 8pc..8pc+7 of this 64-tile: 32-block j = pc>>2, c = (pc&3)*8 + e.
@@ -260,15 +268,18 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
     TANGO_FAIL("attention: ld alignment");
   const bool masked = p.bias != nullptr || (p.Skv % 64) != 0;
   if (p.Sq > 512) {
+    // 4 waves x 32 query rows per workgroup at 3 workgroups/CU.  Wider workgroups (6 or 8 waves sharing one K/V tile
+    // stream, i.e. 1.5-2x fewer L2->LDS bytes per flop) were measured in round 1: 8 waves 10.5 ms vs 9.2 ms per step
+    // at Sq = Skv = 4096 -- occupancy (latency hiding across the softmax phase) matters more than fill bytes here.
     constexpr int QB = 2;
     dim3 grid((unsigned)((p.Sq + 64 * QB - 1) / (64 * QB)), (unsigned)p.heads, (unsigned)p.B);
-    if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_kernel<T, QB, false>), grid, dim3(256), 0, s, p);
+    if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true, 4, 3>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
   } else {
     constexpr int QB = 1;
     dim3 grid((unsigned)((p.Sq + 64 * QB - 1) / (64 * QB)), (unsigned)p.heads, (unsigned)p.B);
-    if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_kernel<T, QB, false>), grid, dim3(256), 0, s, p);
+    if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true, 4, 3>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
   }
   TANGO_HIP(hipGetLastError());
   return 0;

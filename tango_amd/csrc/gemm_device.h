@@ -190,7 +190,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // Here each wave parks 32 rows x (TN*16) fp32 results in its private LDS region (bias / per-step bias / activation
 // already applied, same fp32 arithmetic and order as the direct path -> bit-identical results), then walks the rows
 // with 16-byte pieces: residual read, add, scale, convert, 16-byte store -> TN*16*sizeof(T)-byte contiguous runs.
-// Caller guarantees: all waves are past their last LDS read (barrier), p.epi == EPI_NONE, !p.out_f32, n_base + TN*16 <= N,
+// Caller guarantees: all waves are past their last LDS read (barrier), p.epi is EPI_NONE or EPI_GEGLU, !p.out_f32, n_base + TN*16 <= N,
 // ldo / ldr multiples of 16/sizeof(T), 16-byte aligned out / R.
 template <typename T, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4 (&acc)[TN][TM], const int m_base, const int n_base,
@@ -199,8 +199,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4 
   constexpr int WN = TN * 16;
   constexpr int PITCH = WN * 4 + 16;       // bytes per staged row (+16: spreads rows over the banks)
   constexpr int PPR = WN / EPV;            // 16-byte output pieces per row
-  static_assert((32 * PPR) % 64 == 0, "staged epilogue: 32 rows must split into whole wave passes");
+  static_assert((32 * PPR) % 128 == 0 || (TN & 1), "staged epilogue: 32 rows must split into whole wave passes (also at half width for GEGLU)");
   const int g4 = (lane >> 4) * 4;
+  const bool geglu = p.epi == EPI_GEGLU;
   const float* bias = p.bias;
   const float* bias2 = p.bias2 ? p.bias2 + (int64_t)(p.step_ptr ? *p.step_ptr : 0) * p.bias2_stride : nullptr;
   float cb[TN][4];
@@ -226,21 +227,26 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4 
       const float rb = (bias && p.bias_rows && m < p.M) ? bias[m] : 0.f;
 #pragma unroll
       for (int a = 0; a < TN; ++a) {
+        if (geglu && (a & 1)) continue;
         f32x4 v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha + cb[a][r] + rb;
-        if (p.e_act != ACT_NONE) {
+        if (geglu) {
+          // packed rows: [16 value | 16 gate] column blocks -> output column n/2 (same arithmetic as the direct path)
+          const int ag = a + 1 < TN ? a + 1 : a;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] * gelu_erf_f(acc[ag][b][r] * p.alpha + cb[ag][r]);
+        } else if (p.e_act != ACT_NONE) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.e_act, p.e_slope);
         }
-        *(f32x4*)(stage + row_l * PITCH + (a * 16 + g4) * 4) = v;
+        *(f32x4*)(stage + row_l * PITCH + ((geglu ? (a >> 1) : a) * 16 + g4) * 4) = v;
       }
     }
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < (32 * PPR) / 64; ++it) {
-      const int idx = it * 64 + lane;
-      const int row_l = idx / PPR, pcs = idx - row_l * PPR;
+    const int ppr = geglu ? PPR / 2 : PPR;
+    for (int idx = lane; idx < 32 * ppr; idx += 64) {
+      const int row_l = idx / ppr, pcs = idx - row_l * ppr;
       const int m = m_base + half * 32 + row_l;
       if (m < p.M) {
         float f[EPV];
@@ -250,7 +256,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4 
 #pragma unroll
           for (int r = 0; r < 4; ++r) f[q * 4 + r] = t[r];
         }
-        const int n = n_base + pcs * EPV;
+        const int n = (geglu ? (n_base >> 1) : n_base) + pcs * EPV;
         if (Rb) {
           T rv[EPV];
           __builtin_memcpy(rv, Rb + (int64_t)m * p.ldr + n, 16);
@@ -274,7 +280,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4 
 // host-side predicate for the staged epilogue
 template <typename T> static inline bool epilogue_can_stage(const GemmParams& p) {
   constexpr int EPV = 16 / (int)sizeof(T);
-  if (p.epi != EPI_NONE || p.out_f32 || p.splitk > 1 || p.batch != 1) return false;
+  if ((p.epi != EPI_NONE && p.epi != EPI_GEGLU) || p.out_f32 || p.splitk > 1 || p.batch != 1) return false;
+  if (p.epi == EPI_GEGLU && (p.e_act != ACT_NONE || p.bias_rows)) return false;
   if (p.ldo % EPV != 0 || ((uintptr_t)p.out & 15)) return false;
   if (p.R && (p.ldr % EPV != 0 || ((uintptr_t)p.R & 15))) return false;
   return true;

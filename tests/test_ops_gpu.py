@@ -103,9 +103,9 @@ def test_conv2d_splitk(lib, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
-def test_linear_geglu(lib, dtype):
-    M, C = 150, 64
-    g = torch.Generator().manual_seed(5)
+@pytest.mark.parametrize("M,C", [(150, 64), (1000, 320), (520, 640)])   # the larger two reach the LDS-DMA kernel when forced
+def test_linear_geglu(lib, dtype, M, C):
+    g = torch.Generator().manual_seed(5 + M)
     x = quant(torch.randn(M, C, generator=g), dtype)
     w = quant(torch.randn(8 * C, C, generator=g) / C ** 0.5, dtype)
     b = torch.randn(8 * C, generator=g)
