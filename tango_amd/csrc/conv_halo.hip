@@ -1,4 +1,5 @@
-// 3x3 / stride 1 / pad 1 convolution over channels-last activations with HALO REUSE (gfx950).
+// 3x3 / stride 1 / pad 1 convolution (optionally over a nearest-x2 upsampled input) over channels-last activations
+// with HALO REUSE (gfx950).
 //
 // Why: the generic implicit-GEMM kernel (gemm.hip) re-gathers the 256-pixel activation tile once per tap, i.e. 9x per
 // 128-byte channel chunk.  PMC (profiles/r1_v16_pmc_conv_l0.txt) shows that kernel waiting on LDS-DMA arrival:
@@ -76,8 +77,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GemmParams p, c
       const int seg = h / SEG, rem = h - seg * SEG;
       const int hy = rem / HW2, hx = rem - hy * HW2;
       const int y = y0 + hy - 1, x = hx - 1;
+      // fused nearest x2 upsampling (p.ups): the halo lives on the upsampled grid, pixel (y, x) reads source (y>>1, x>>1)
       if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)Wd)
-        a_src[t] = ((((int64_t)(b0 + seg) * H + y) * Wd + x) * p.lda + pc * EPV) * (int64_t)sizeof(T);
+        a_src[t] = ((((int64_t)(b0 + seg) * p.Hin + (y >> p.ups)) * p.Win + (x >> p.ups)) * p.lda + pc * EPV) * (int64_t)sizeof(T);
     }
   }
   // weight DMA sources
@@ -235,7 +237,7 @@ bool conv_halo_ok(int dtype, const GemmParams& p) {
   static const bool off = getenv("TANGO_NO_HALO_CONV") != nullptr;      // experiment switch
   if (off) return false;
   const int esz = dtype == DT_F32 ? 4 : 2;
-  if (p.mode != GATHER_2D || p.stride != 1 || p.ups != 0 || p.Hin != p.H || p.Win != p.Wd) return false;
+  if (p.mode != GATHER_2D || p.stride != 1 || p.ups < 0 || p.ups > 1 || (p.Hin << p.ups) != p.H || (p.Win << p.ups) != p.Wd) return false;
   if (p.batch != 1 || p.splitk > 1 || p.a_act != ACT_NONE || p.epi == EPI_GEGLU || p.epi == EPI_VT) return false;
   if ((p.Cin * esz) % 128 != 0 || p.K != 9 * p.Cin || p.M % 256 != 0) return false;
   const int bn = p.N % 160 == 0 ? 160 : 128;

@@ -183,13 +183,25 @@ def test_conv2d(lib, dtype, Cin, Cout, H, W, stride, ups):
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(16, 64, 640, 64, 16), (32, 128, 640, 64, 8), (64, 192, 640, 64, 4),
                                             (32, 64, 512, 8, 64), (256, 64, 512, 8, 8), (2, 64, 1280, 256, 16)])
 def test_conv2d_halo(lib, dtype, B, Cin, Cout, H, W):
+    _conv2d_halo_case(lib, dtype, B, Cin, Cout, H, W, 0)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(16, 64, 640, 32, 8), (32, 128, 640, 32, 4), (8, 64, 512, 16, 32)])
+def test_conv2d_halo_upsampled(lib, dtype, B, Cin, Cout, H, W):
+    """nearest x2 upsample fused into the halo gather (Upsample2D, diffusers resnet.py:90-137): H, W are the SOURCE dims"""
+    _conv2d_halo_case(lib, dtype, B, Cin, Cout, H, W, 1)
+
+
+def _conv2d_halo_case(lib, dtype, B, Cin, Cout, H, W, ups):
     g = torch.Generator().manual_seed(Cin * Cout + H + W)
     x = quant(torch.randn(B, Cin, H, W, generator=g), dtype)
     w = quant(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5, dtype)
     b = torch.randn(Cout, generator=g)
-    ref = F.conv2d(x, w, b, padding=1)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    ref = F.conv2d(xin, w, b, padding=1)
     out = torch.empty(ref.shape, device="cuda")
-    check(lib, lib.tango_op_conv2d(DT[dtype], ptr(dev(x)), ptr(dev(w)), ptr(dev(b)), ptr(out), B, Cin, H, W, Cout, 1, 0, None))
+    check(lib, lib.tango_op_conv2d(DT[dtype], ptr(dev(x)), ptr(dev(w)), ptr(dev(b)), ptr(out), B, Cin, H, W, Cout, 1, ups, None))
     close(out, ref, dtype, "conv2d halo")
 
 
