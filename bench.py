@@ -33,7 +33,7 @@ GFLOP_VOCODER_PER_SAMPLE = 1027.04
 AUDIO_SECONDS_PER_SAMPLE = 163872 / 16000.0
 PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
 #: HBM-side bytes of one UNet-step launch at B=32 fp16 from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-#: WRITE_SIZE, KiB units), measured offline: profiles/r1_final_pmc_hbm_traffic_unet_step.txt.  Scales ~linearly with B.
+#: WRITE_SIZE, KiB units), measured offline: profiles/r1_v18_pmc_hbm_traffic_unet_step.txt.  Scales ~linearly with B.
 HBM_BYTES_PER_STEP_B32_FP16 = 156.4e9
 
 
