@@ -96,12 +96,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
+    torch.cuda.set_device(local_rank)          # before the process group: RCCL binds its communicator to the current device
+    device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
 
     from tango_amd.autoencoder import AutoencoderKL
     from tango_amd.engine import HIFIGAN_CONFIG, UNET_CONFIG_LARGE, UNET_CONFIG_XL, VAE_CONFIG
@@ -154,14 +154,14 @@ def main():
         one_pass()
     denoise_ms.clear()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wav = one_pass()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)

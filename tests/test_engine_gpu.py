@@ -178,6 +178,52 @@ def test_denoise_loop_tiny(dtype, sched_name):
     assert tot > 0 and per > 0
 
 
+@pytest.mark.parametrize("guidance,pred,B", [(1.0, "v_prediction", 3), (0.0, "v_prediction", 1), (3.0, "epsilon", 3), (7.5, "sample", 1)])
+def test_denoise_loop_edge_cases(guidance, pred, B):
+    """models.py:224-249 off the beaten path: guidance <= 1 runs WITHOUT the unconditional twin (UNet batch B, not 2B;
+    models.py:231,236), odd batches, epsilon / sample prediction types (scheduling_ddpm.py:299-309)."""
+    cfg = O.UNET_CONFIG_TINY
+    e = unet_engine("tiny", "fp32")
+    L, N = 7, 3
+    nb = 2 * B if guidance > 1.0 else B
+    enc, mask = text_inputs(nb, L, cfg["cross_attention_dim"], 57 + B)
+    g = torch.Generator().manual_seed(58)
+    lat0 = torch.randn(B, 8, 256, 16, generator=g)
+    noises = torch.randn(N, B, 8, 256, 16, generator=g)
+    conf = dict(O.SD21_SCHEDULER, prediction_type=pred)
+    osch = O.DDPMOracle(**conf)
+    keys = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "prediction_type", "clip_sample", "variance_type")
+    sch = DDPMScheduler.from_config(dict({k: SD21_SCHEDULER_CONFIG[k] for k in keys}, prediction_type=pred))
+    ref = O.denoise_loop(unet_sd("tiny"), cfg, osch, enc, mask, lat0.clone(), N, guidance, noises=list(noises), prefix="unet.")
+    sch.set_timesteps(N)
+    outs = []
+    for use_graph in (True, False):
+        lat = lat0.clone().cuda()
+        e.denoise(lat, enc.cuda(), mask.cuda(), sch.timesteps.numpy(), sch.coef_table(), guidance,
+                  prediction_type=pred, rule=sch.rule, noise=noises.cuda(), use_graph=use_graph)
+        torch.cuda.synchronize()
+        outs.append(lat.cpu())
+    assert torch.equal(outs[0], outs[1])
+    err = (outs[0] - ref).abs().max().item()
+    print("denoise edge g=%s %s B=%d max abs err %.3e (|ref| max %.2f)" % (guidance, pred, B, err, ref.abs().max()))
+    assert err <= 1e-2 * max(1.0, ref.abs().max().item() / 4)
+
+
+def test_denoise_rejects_bad_arguments():
+    """error behaviour at the boundary: wrong embedding batch for the CFG mode, more than 1000 steps (scheduling_ddpm.py:193-198)"""
+    cfg = O.UNET_CONFIG_TINY
+    e = unet_engine("tiny", "fp32")
+    keys = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "prediction_type", "clip_sample", "variance_type")
+    sch = DDPMScheduler.from_config({k: SD21_SCHEDULER_CONFIG[k] for k in keys})
+    with pytest.raises(ValueError):
+        sch.set_timesteps(1001)
+    sch.set_timesteps(2)
+    enc, mask = text_inputs(2, 5, cfg["cross_attention_dim"], 3)
+    lat = torch.randn(2, 8, 256, 16).cuda()
+    with pytest.raises((ValueError, RuntimeError)):      # guidance 3 needs [uncond; cond] = 4 rows for 2 latents
+        e.denoise(lat, enc.cuda(), mask.cuda(), sch.timesteps.numpy(), sch.coef_table(), 3.0, rule=sch.rule, seed=1)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
 def test_vae_and_vocoder(dtype):
     """decode_first_stage + decode_to_waveform: full-size mel-VAE decoder and HiFi-GAN (B = 2)."""
