@@ -117,3 +117,45 @@ def test_scheduler_surface_and_errors():
                       prediction_type="v_prediction", clip_sample=False, set_alpha_to_one=False, steps_offset=1)
     d.set_timesteps(200)
     assert d.timesteps.tolist() == list(range(996, 0, -5)) and d.rule == "ddim"
+
+
+def test_batch_inference_driver_writes_reference_layout(tmp_path):
+    """generation + save half of inference.py:127-176 with a test double for the generator (no GPU)."""
+    import json
+    import wave
+
+    import numpy as np
+
+    from tango_amd import batch_inference as BI
+
+    tf = tmp_path / "prompts.json"
+    tf.write_text("\n".join(json.dumps({"captions": c, "id": i}) for i, c in enumerate(["a dog barks", "rain", "a car passes"])) + "\n")
+    prompts = BI.read_prompts(str(tf), "captions", prefix="gen: ")
+    assert prompts == ["gen: a dog barks", "gen: rain", "gen: a car passes"]
+
+    class Fake:
+        def __init__(self):
+            self.calls = []
+
+        def generate_for_batch(self, prompts, steps, guidance, samples, batch_size):
+            self.calls.append((len(prompts), steps, guidance, samples, batch_size))
+            waves = [np.full(1600, 100 * j + k, np.int16) for j in range(len(prompts)) for k in range(samples)]
+            return waves if samples == 1 else [waves[i:i + samples] for i in range(0, len(waves), samples)]
+
+    g = Fake()
+    rec = BI.generate_and_save(g, prompts, num_steps=10, guidance=3, batch_size=2, num_samples=1, out_root=str(tmp_path / "outputs"), exp_id="7")
+    assert g.calls == [(3, 10, 3, 1, 2)] and rec["Test Instances"] == 3 and rec["Steps"] == 10
+    for j in range(3):
+        with wave.open(str(tmp_path / "outputs" / "7_steps_10_guidance_3" / ("output_%d.wav" % j)), "rb") as w:
+            assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 16000, 1600)
+            assert np.frombuffer(w.readframes(1600), "<i2")[0] == 100 * j
+    rec2 = BI.generate_and_save(g, prompts, num_steps=5, guidance=2.5, batch_size=8, num_samples=2, out_root=str(tmp_path / "outputs"), exp_id="8")
+    for i in (1, 2):
+        with wave.open(str(tmp_path / "outputs" / "8_steps_5_guidance_2.5" / ("rank_%d" % i) / "output_2.wav"), "rb") as w:
+            assert np.frombuffer(w.readframes(4), "<i2")[0] == 200 + (i - 1)
+    lines = [l for l in (tmp_path / "outputs" / "summary.jsonl").read_text().split("\n") if l.strip()]
+    assert len(lines) == 2 and json.loads(lines[1])["Samples Per Prompt"] == 2 and abs(rec2["audio_seconds"] - 0.6) < 1e-9
+    import pytest
+    with pytest.raises(ValueError):
+        BI.write_wav(str(tmp_path / "x.wav"), np.zeros(4, np.float32))
+    assert BI.generate_and_save(g, [], out_root=str(tmp_path / "o2"), exp_id="9")["Test Instances"] == 0
