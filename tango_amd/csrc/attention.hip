@@ -177,25 +177,39 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       float mt = -1.0e30f;
+      float mnew;
+      if (MASKED) {
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float sv = sacc[qb][kb][r] * sc2;
-          if (MASKED) sv += bv[MASKED ? kb : 0][r];
-          sacc[qb][kb][r] = sv;
-          mt = fmaxf(mt, sv);
-        }
-      mt = fmaxf(mt, __shfl_xor(mt, 16));
-      mt = fmaxf(mt, __shfl_xor(mt, 32));
-      const float mnew = fmaxf(mrow[qb], mt);
+          for (int r = 0; r < 4; ++r) {
+            const float sv = sacc[qb][kb][r] * sc2 + bv[MASKED ? kb : 0][r];
+            sacc[qb][kb][r] = sv;
+            mt = fmaxf(mt, sv);
+          }
+        mt = fmaxf(mt, __shfl_xor(mt, 16));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        mnew = fmaxf(mrow[qb], mt);
+      } else {
+        // unmasked: max(sc2 * s) == sc2 * max(s) (sc2 > 0), so the scale is applied once to the maximum and otherwise
+        // rides along in the exponent's FMA -- 16 multiplies per query block and tile less on the VALU, which is the
+        // co-limiter of this kernel (34 v_exp + ~150 VALU vs 32 MFMA per tile)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mt = fmaxf(mt, sacc[qb][kb][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 16));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        mnew = fmaxf(mrow[qb], mt * sc2);
+      }
       const float alpha = __builtin_amdgcn_exp2f(mrow[qb] - mnew);
       float rs = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(sacc[qb][kb][r] - mnew);
+          const float pv = MASKED ? __builtin_amdgcn_exp2f(sacc[qb][kb][r] - mnew)
+                                  : __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qb][kb][r], sc2, -mnew));
           sacc[qb][kb][r] = pv;
           rs += pv;
         }
@@ -270,7 +284,8 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
   if (p.Sq > 512) {
     // 4 waves x 32 query rows per workgroup at 3 workgroups/CU.  Wider workgroups (6 or 8 waves sharing one K/V tile
     // stream, i.e. 1.5-2x fewer L2->LDS bytes per flop) were measured in round 1: 8 waves 10.5 ms vs 9.2 ms per step
-    // at Sq = Skv = 4096 -- occupancy (latency hiding across the softmax phase) matters more than fill bytes here.
+    // at Sq = Skv = 4096; 48 or 64 query rows per wave at 2 waves/SIMD: 9.2 / 10.1 ms -- the kernel is VALU (softmax)
+    // co-limited, not fill-limited.
     constexpr int QB = 2;
     dim3 grid((unsigned)((p.Sq + 64 * QB - 1) / (64 * QB)), (unsigned)p.heads, (unsigned)p.B);
     if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true, 4, 3>), grid, dim3(256), 0, s, p);
