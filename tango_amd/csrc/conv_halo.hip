@@ -27,9 +27,11 @@ namespace tango {
 static constexpr int HALO_MAX_ROWS = 400;   // halo pixels per tile the LDS budget allows (2 buffers)
 static constexpr int HALO_NA = 7;           // halo DMA pieces per wave per channel chunk (8 waves x 7 x 8 rows >= 400)
 
-template <typename T, int BN>
+// ABL = true compiles the ablation hooks in (TANGO_HALO_ABL, tools/halo_ablation.sh); the product instantiation has none.
+template <typename T, int BN, bool ABL>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GemmParams p, const unsigned char* zero_page, const int SR,
-                                                           const int nseg, const int abytes, const int abl, const int staged) {
+                                                           const int nseg, const int abytes, const int abl_arg, const int staged) {
+  const int abl = ABL ? abl_arg : 0;
   constexpr int EPV = 16 / (int)sizeof(T);
   constexpr int BM = 256, BKB = 128;
   constexpr int BK = BKB / (int)sizeof(T);
@@ -255,14 +257,14 @@ static int launch_halo_cfg(const GemmParams& p, const unsigned char* zero_page, 
   if (!halo_geom(p, g)) TANGO_FAIL("conv_halo: unsupported geometry");
   const int abytes = ((g.halo + 7) / 8) * 1024;
   const int lds = 2 * abytes + 3 * BN * 128;
-  auto kfn = conv3x3_halo_kernel<T, BN>;
+  static const int abl = getenv("TANGO_HALO_ABL") ? atoi(getenv("TANGO_HALO_ABL")) : 0;   // ablation study switch
+  auto kfn = abl ? conv3x3_halo_kernel<T, BN, true> : conv3x3_halo_kernel<T, BN, false>;
   static int attr_lds = 0;
   if (lds > attr_lds) {
     TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_lds = lds;
   }
   const int tiles = (p.M / 256) * (p.N / BN);
-  static const int abl = getenv("TANGO_HALO_ABL") ? atoi(getenv("TANGO_HALO_ABL")) : 0;   // ablation study switch
   static const bool no_stage = getenv("TANGO_NO_STAGED_EPILOGUE") != nullptr;   // experiment switch
   const int staged = (!no_stage && epilogue_can_stage<T>(p)) ? 1 : 0;
   hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(512), lds, s, p, zero_page, g.SR, g.nseg, abytes, abl, staged);
