@@ -1,3 +1,9 @@
+"""Stress / localisation script for the streaming linear with folded LayerNorm (M=5000, N=1920, K=640, fp16).
+Runs tango_op_linear_ln REPS times on the same inputs and prints, per repetition, how many outputs deviate from the
+torch reference by more than 2 % of max|ref| and where (rows / columns).  Used in round 1 to characterise the
+codegen-sensitive race described in DESIGN.md section 5 ("open issue"): a healthy build prints `bad elems 0` every time.
+usage (GPU box): REPS=40 python tools/diag_linear_ln.py
+"""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import ctypes as C, torch, torch.nn.functional as F
