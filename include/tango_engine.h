@@ -159,6 +159,11 @@ int tango_op_attention(int dtype, const float* q, const float* k, const float* v
 int tango_op_sched_step(float* latents, const float* model_out_nchw, const float* noise, const float* coef8, int B, int C, int HW,
                         int cfg, float guidance, int pred_type, int rule, int clip, float clip_range, void* stream);
 
+/* the N(0,1) values the denoise loop's device Philox generator injects at loop index `step` for global samples
+ * [sample_offset, sample_offset + B): out fp32 [B, C, HW] (replaces randn_tensor inside DDPMScheduler.step,
+ * mustango/diffusers/src/diffusers/schedulers/scheduling_ddpm.py:331-338, for throughput runs) */
+int tango_op_philox_normal(float* out, int B, int C, int HW, int step, uint64_t seed, int sample_offset, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

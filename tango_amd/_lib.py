@@ -82,7 +82,7 @@ SYMBOLS = [
     "tango_engine_vae_decode", "tango_engine_vocode", "tango_engine_vocoder_samples",
     "tango_engine_last_denoise_ms", "tango_engine_profile_unet", "tango_op_conv2d", "tango_op_linear", "tango_op_linear_ln", "tango_op_conv1d",
     "tango_op_conv_transpose1d", "tango_op_groupnorm", "tango_op_layernorm", "tango_op_attention",
-    "tango_op_sched_step",
+    "tango_op_sched_step", "tango_op_philox_normal",
 ]
 
 _lib = None
@@ -125,6 +125,7 @@ def load():
     lib.tango_op_layernorm.argtypes = [ci, vp, vp, vp, vp, ci, ci, cf, vp]
     lib.tango_op_attention.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp]
     lib.tango_op_sched_step.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, cf, ci, ci, ci, cf, vp]
+    lib.tango_op_philox_normal.argtypes = [vp, ci, ci, ci, ci, C.c_uint64, ci, vp]
     _lib = lib
     return lib
 

@@ -194,8 +194,11 @@ struct SchedParams {
   unsigned long long seed;
   int sample_offset;     // global sample index of local sample 0 (multi-GPU invariant noise)
 };
-int launch_sched_step(int dtype, const SchedParams& p, hipStream_t s);
+// `dev_params` is a DEVICE copy of SchedParams; the grid covers max_positions >= B*HW (one thread per latent position)
+int launch_sched_step(int dtype, const SchedParams* dev_params, int max_positions, hipStream_t s);
 int launch_step_inc(int* step_ptr, hipStream_t s);
+// test hook: the N(0,1) draws of sched_step at loop index `step` -> out fp32 [B][C][HW]
+int launch_philox_normal(float* out, int B, int C, int HW, int step, unsigned long long seed, int sample_offset, hipStream_t s);
 
 // latents fp32 NCHW [B,C,HW] -> T NHWC [rep*B, HW, ld] (replicated `rep` times along batch), zero-pads C..ld? no: writes C channels
 int launch_nchw_to_nhwc(int dtype, const float* src, void* dst, int64_t ld, int B, int C, int HW, int rep, float scale, hipStream_t s);

@@ -35,10 +35,23 @@ __device__ __forceinline__ void box_muller(unsigned a, unsigned b, float& n0, fl
   n0 = r * c; n1 = r * s;
 }
 
+// four N(0,1) draws for channels 4*c4 .. 4*c4+3 of latent position hw of GLOBAL sample `sample` at loop index `step`:
+// the Philox counter is (hw, c4, sample, step), the key is the 64-bit seed -> independent of batch split / GPU count
+__device__ __forceinline__ void philox_normal4(int hw, int c4, int sample, int step, unsigned long long seed, float (&n)[4]) {
+  unsigned r[4];
+  philox4x32((unsigned)hw, (unsigned)c4, (unsigned)sample, (unsigned)step, (unsigned)seed, (unsigned)(seed >> 32), r);
+  box_muller(r[0], r[1], n[0], n[1]);
+  box_muller(r[2], r[3], n[2], n[3]);
+}
+
+// The parameter block is read from DEVICE memory (wave-uniform scalar loads): the launch itself then carries only one
+// pointer, so the captured hipGraph of a denoise step stays valid when the caller's latents / noise pointers, guidance
+// or prediction type change between calls (engine.hip refreshes the block with one hipMemcpyAsync per call).
 template <typename T>
-__global__ __launch_bounds__(256) void sched_step_kernel(const SchedParams p) {
+__global__ __launch_bounds__(256) void sched_step_kernel(const SchedParams* __restrict__ pp) {
   // plain operators + contract(off): the HIP _rn intrinsics are inlined header operators that still fuse
 #pragma clang fp contract(off)
+  const SchedParams p = *pp;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= p.B * p.HW) return;
   const int b = idx / p.HW, hw = idx - b * p.HW;
@@ -50,6 +63,7 @@ __global__ __launch_bounds__(256) void sched_step_kernel(const SchedParams p) {
   const float* ec = p.cfg ? p.eps + ((int64_t)(p.B + b) * p.HW + hw) * C : nullptr;
   T* xo0 = (T*)p.xin + ((int64_t)b * p.HW + hw) * p.xin_ld;
   T* xo1 = p.cfg ? (T*)p.xin + ((int64_t)(p.B + b) * p.HW + hw) * p.xin_ld : nullptr;
+  float nrm[4] = {0.f, 0.f, 0.f, 0.f};
   for (int c = 0; c < C; ++c) {
     float* lp = p.lat + ((int64_t)b * C + c) * p.HW + hw;
     const float x = *lp;
@@ -66,14 +80,8 @@ __global__ __launch_bounds__(256) void sched_step_kernel(const SchedParams p) {
       if (p.noise) {
         nz = p.noise[(int64_t)step * p.B * C * p.HW + ((int64_t)b * C + c) * p.HW + hw];
       } else {
-        unsigned r[4];
-        philox4x32((unsigned)hw, (unsigned)(c >> 2), (unsigned)(p.sample_offset + b), (unsigned)step,
-                   (unsigned)p.seed, (unsigned)(p.seed >> 32), r);
-        float n0, n1, n2, n3;
-        box_muller(r[0], r[1], n0, n1);
-        box_muller(r[2], r[3], n2, n3);
-        const int k = c & 3;
-        nz = k == 0 ? n0 : k == 1 ? n1 : k == 2 ? n2 : n3;
+        if ((c & 3) == 0) philox_normal4(hw, c >> 2, p.sample_offset + b, step, p.seed, nrm);   // one draw per 4 channels
+        nz = nrm[c & 3];
       }
     }
     if (p.rule == 0) {
@@ -92,14 +100,34 @@ __global__ __launch_bounds__(256) void sched_step_kernel(const SchedParams p) {
     xo0[c] = tv;
     if (xo1) xo1[c] = tv;
   }
+  // the last workgroup to get here could bump the step counter, but every block of THIS launch and of the next UNet
+  // launch reads it: the increment stays a separate 1-thread launch (captured in the same hipGraph, engine.hip)
 }
 
-int launch_sched_step(int dtype, const SchedParams& p, hipStream_t s) {
-  const unsigned nb = (unsigned)((p.B * p.HW + 255) / 256);
+// test hook: the N(0,1) draws sched_step_kernel makes at loop index `step` for samples [sample_offset, sample_offset + B)
+__global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, int B, int C, int HW, int step,
+                                                            unsigned long long seed, int sample_offset) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * HW) return;
+  const int b = idx / HW, hw = idx - b * HW;
+  float nrm[4];
+  for (int c = 0; c < C; ++c) {
+    if ((c & 3) == 0) philox_normal4(hw, c >> 2, sample_offset + b, step, seed, nrm);
+    out[((int64_t)b * C + c) * HW + hw] = nrm[c & 3];
+  }
+}
+int launch_philox_normal(float* out, int B, int C, int HW, int step, unsigned long long seed, int sample_offset, hipStream_t s) {
+  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((B * HW + 255) / 256)), dim3(256), 0, s, out, B, C, HW, step, seed, sample_offset);
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_sched_step(int dtype, const SchedParams* dev_params, int max_positions, hipStream_t s) {
+  const unsigned nb = (unsigned)((max_positions + 255) / 256);   // >= B*HW of the block; surplus threads exit
   switch (dtype) {
-    case DT_F32: hipLaunchKernelGGL((sched_step_kernel<float>), dim3(nb), dim3(256), 0, s, p); break;
-    case DT_F16: hipLaunchKernelGGL((sched_step_kernel<f16>), dim3(nb), dim3(256), 0, s, p); break;
-    case DT_BF16: hipLaunchKernelGGL((sched_step_kernel<bf16>), dim3(nb), dim3(256), 0, s, p); break;
+    case DT_F32: hipLaunchKernelGGL((sched_step_kernel<float>), dim3(nb), dim3(256), 0, s, dev_params); break;
+    case DT_F16: hipLaunchKernelGGL((sched_step_kernel<f16>), dim3(nb), dim3(256), 0, s, dev_params); break;
+    case DT_BF16: hipLaunchKernelGGL((sched_step_kernel<bf16>), dim3(nb), dim3(256), 0, s, dev_params); break;
     default: TANGO_FAIL("sched_step: bad dtype");
   }
   TANGO_HIP(hipGetLastError());

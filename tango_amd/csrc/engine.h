@@ -202,6 +202,7 @@ class Engine {
 
   // ---- runtime state ----
   int* d_step = nullptr;
+  SchedParams* d_sched = nullptr;   // device copy of the current call's scheduler parameter block
   int64_t* d_ts = nullptr;       // [max_steps]
   float* d_coef = nullptr;       // [max_steps][8]
   float* d_sin = nullptr;        // [max_steps][ch0]

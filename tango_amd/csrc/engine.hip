@@ -579,12 +579,13 @@ int Engine::init() {
     build_unet_weights();
     const int temb = cfg.unet_channels[0] * 4;
     d_step = (int*)dmalloc(256);
+    d_sched = (SchedParams*)dmalloc(sizeof(SchedParams));
     d_ts = (int64_t*)dmalloc((size_t)max_steps * 8);
     d_coef = (float*)dmalloc((size_t)max_steps * 8 * 4);
     d_sin = (float*)dmalloc((size_t)max_steps * cfg.unet_channels[0] * 4);
     d_t1 = (float*)dmalloc((size_t)max_steps * temb * 4);
     d_temb = (float*)dmalloc((size_t)max_steps * temb * 4);
-    if (!d_step || !d_ts || !d_coef || !d_sin || !d_t1 || !d_temb) return -1;
+    if (!d_step || !d_sched || !d_ts || !d_coef || !d_sin || !d_t1 || !d_temb) return -1;
   }
   if (cfg.vae_levels > 0) build_vae_weights();
   if (cfg.voc_n_ups > 0) build_voc_weights();
@@ -608,6 +609,7 @@ int Engine::set_weight(const char* name, const float* dev, const int64_t* shape,
     TANGO_FAIL(e + ")");
   }
   TANGO_TRY(s.pack(dev, 0));
+  temb_ts.clear();   // time-embedding tables are derived from weights: never reuse them across a reload
   TANGO_HIP(hipStreamSynchronize(0));   // the caller may free/reuse `dev` right after this returns
   s.set = true;
   return 0;
@@ -633,6 +635,7 @@ int Engine::finalize_weights() {
     TANGO_TRY(fold_ln(x->ff1, x->ln3));
   }
   TANGO_HIP(hipDeviceSynchronize());
+  temb_ts.clear();
   finalized = true;
   return 0;
 }
@@ -854,29 +857,37 @@ int Engine::denoise(const tango_denoise_args_t& a, hipStream_t s) {
   UNetPlan* P;
   TANGO_TRY(get_unet_plan(B2, a.text_len, &P));
   TANGO_TRY(ensure_temb(a.timesteps, a.num_steps, s));
-  TANGO_HIP(hipMemcpyAsync(d_coef, a.coef, (size_t)a.num_steps * 8 * 4, hipMemcpyHostToDevice, s));
-  TANGO_HIP(hipStreamSynchronize(s));
-  TANGO_HIP(hipMemsetAsync(d_step, 0, 4, s));
-  TANGO_TRY(bind_text(*P, a.prompt_embeds, a.prompt_mask, s));
   const int HW = cfg.latent_h * cfg.latent_w;
   const int C = cfg.unet_in_channels;
-  TANGO_TRY(launch_fill_zero(P->xin, (size_t)B2 * HW * 8 * esz, s));
-  TANGO_TRY(launch_nchw_to_nhwc(dt, a.latents, P->xin, 8, B, C, HW, cfg_on ? 2 : 1, 1.0f, s));
-
   SchedParams sp;
   sp.lat = a.latents; sp.eps = P->eps; sp.xin = P->xin; sp.xin_ld = 8;
   sp.noise = a.noise; sp.coef = d_coef; sp.step_ptr = d_step;
   sp.B = B; sp.C = C; sp.HW = HW; sp.cfg = cfg_on ? 1 : 0; sp.guidance = a.guidance_scale;
   sp.pred_type = a.prediction_type; sp.rule = a.rule; sp.clip = a.clip_sample; sp.clip_range = a.clip_sample_range;
   sp.seed = a.seed; sp.sample_offset = a.sample_offset;
+  // per-call tables and the scheduler parameter block live in device memory, so the captured graph of one denoise
+  // step (UNet + CFG/scheduler update + step counter) is independent of the call's pointers and scalars
+  TANGO_HIP(hipMemcpyAsync(d_coef, a.coef, (size_t)a.num_steps * 8 * 4, hipMemcpyHostToDevice, s));
+  TANGO_HIP(hipMemcpyAsync(d_sched, &sp, sizeof(SchedParams), hipMemcpyHostToDevice, s));
+  TANGO_HIP(hipStreamSynchronize(s));   // both sources are pageable / transient host memory
+  TANGO_HIP(hipMemsetAsync(d_step, 0, 4, s));
+  TANGO_TRY(bind_text(*P, a.prompt_embeds, a.prompt_mask, s));
+  TANGO_TRY(launch_fill_zero(P->xin, (size_t)B2 * HW * 8 * esz, s));
+  TANGO_TRY(launch_nchw_to_nhwc(dt, a.latents, P->xin, 8, B, C, HW, cfg_on ? 2 : 1, 1.0f, s));
 
+  // one denoise step = UNet forward, fused CFG combine + scheduler update (writes the next UNet input), step counter++
+  auto run_step = [&](hipStream_t st) -> int {
+    TANGO_TRY(P->step.run(st));
+    TANGO_TRY(launch_sched_step(dt, d_sched, B2 * HW, st));
+    return launch_step_inc(d_step, st);
+  };
   if (a.use_graph && !P->exec) {
-    // capture the UNet step once per (B2, L) plan; every per-step quantity is read through d_step
+    // capture the whole step once per (B2, L) plan; every per-step quantity is read through d_step / d_sched
     // (captured on an engine-owned stream: the caller's stream may be the legacy null stream,
     // which cannot be captured; the instantiated graph is then launched on the caller's stream)
     if (!cap_stream) TANGO_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     TANGO_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeRelaxed));
-    int rc = P->step.run(cap_stream);
+    int rc = run_step(cap_stream);
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(cap_stream, &g);
     if (rc != 0) return rc;
@@ -887,9 +898,7 @@ int Engine::denoise(const tango_denoise_args_t& a, hipStream_t s) {
   TANGO_HIP(hipEventRecord(ev0, s));
   for (int i = 0; i < a.num_steps; ++i) {
     if (a.use_graph) TANGO_HIP(hipGraphLaunch(P->exec, s));
-    else TANGO_TRY(P->step.run(s));
-    TANGO_TRY(launch_sched_step(dt, sp, s));
-    TANGO_TRY(launch_step_inc(d_step, s));
+    else TANGO_TRY(run_step(s));
   }
   TANGO_HIP(hipEventRecord(ev1, s));
   last_steps = a.num_steps;

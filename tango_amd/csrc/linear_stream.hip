@@ -48,7 +48,9 @@ template <typename T> __device__ __forceinline__ void frag_stats(const u32x4& v,
 }
 
 // KS = K*sizeof(T)/64 k-steps per row, TN = 16-column tiles per panel (BN = 16*TN); ring of R = 10 k-steps
-template <typename T, int KS, int TN>
+// LN (folded LayerNorm) is a template parameter: a wave-uniform runtime test in the micro-step loop is not free
+// (the halo conv gained 7-9 % when its ablation tests were compiled out).
+template <typename T, int KS, int TN, bool LN>
 __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) {
   constexpr int R = (TN > 5) ? 5 : 10;         // ring depth in k-steps (register budget: acc 8*TN + ring 8*R)
   constexpr int TM = 2;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
     float* cstw = (float*)(wlds + BN * ROWB + 8 * 16 * (BN * (int)sizeof(T) + 16));
     for (int i = tid; i < BN; i += 512) {
       cstw[i] = p.bias ? p.bias[n0 + i] : 0.f;
-      cstw[BN + i] = p.ln_fold ? p.wsum[n0 + i] : 0.f;
+      cstw[BN + i] = LN ? p.wsum[n0 + i] : 0.f;
     }
   }
   __syncthreads();
@@ -147,13 +149,18 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
 #pragma unroll
       for (int a = 0; a < H; ++a) wf[nb_][a] = *(const u32x4*)(wbase + (hn * H + a) * 16 * ROWB + koff_of(ksn));
       __builtin_amdgcn_sched_barrier(0);
-      if (p.ln_fold && hh == 0) { frag_stats<T>(xf[slot][0], ssum[0], ssq[0]); frag_stats<T>(xf[slot][1], ssum[1], ssq[1]); }
+      if (LN && hh == 0) { frag_stats<T>(xf[slot][0], ssum[0], ssq[0]); frag_stats<T>(xf[slot][1], ssum[1], ssq[1]); }
 #pragma unroll
       for (int a = 0; a < H; ++a) {
         SMma<T>::run(acc[hh * H + a][0], wf[cb_][a], xf[slot][0]);
         SMma<T>::run(acc[hh * H + a][1], wf[cb_][a], xf[slot][1]);
       }
       __builtin_amdgcn_sched_barrier(0);
+      // keep the weight fragments of this micro-step allocated until its VALU work is done (see DESIGN.md section 5:
+      // tools/mfma_war_repro.hip shows that a VALU write right behind an MFMA's source operands is safe on gfx950, so
+      // this is belt and braces, kept because the templated kernel was validated in this form)
+#pragma unroll
+      for (int a = 0; a < H; ++a) asm volatile("" ::"v"(wf[cb_][a]));
       if (hh == NH - 1) {
         // refill the ring slot with the k-step that is R ahead in this wave's stream
 #pragma unroll
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
 
     // ---- epilogue for rows grp*32 .. +31, columns n0 .. n0+BN ----
     float mean[TM] = {0.f, 0.f}, rstd[TM] = {1.f, 1.f};
-    if (p.ln_fold) {
+    if (LN) {
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
         float s = ssum[tm], q = ssq[tm];
@@ -279,12 +286,12 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
   }
 }
 
-template <typename T, int KS, int TN>
+template <typename T, int KS, int TN, bool LN>
 static int stream_launch(const GemmParams& p, hipStream_t s) {
   constexpr int BN = TN * 16;
   constexpr int LDS = BN * KS * 64 + 8 * 16 * (BN * (int)sizeof(T) + 16) + 2 * BN * 4;   // weight panel + per-wave output staging + constants
   static bool attr_set = false;
-  auto kfn = lin_stream_kernel<T, KS, TN>;
+  auto kfn = lin_stream_kernel<T, KS, TN, LN>;
   if (!attr_set) {
     TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
@@ -330,8 +337,8 @@ bool linear_stream_ok(int dtype, const GemmParams& p) {
 template <typename T>
 static int stream_t(const GemmParams& p, hipStream_t s) {
   const int rowb = p.K * (int)sizeof(T);
-  if (rowb == 640) return stream_launch<T, 10, 10>(p, s);
-  if (rowb == 1280) return stream_launch<T, 20, 5>(p, s);
+  if (rowb == 640) return p.ln_fold ? stream_launch<T, 10, 10, true>(p, s) : stream_launch<T, 10, 10, false>(p, s);
+  if (rowb == 1280) return p.ln_fold ? stream_launch<T, 20, 5, true>(p, s) : stream_launch<T, 20, 5, false>(p, s);
   TANGO_FAIL("linear_stream: unsupported K");
 }
 

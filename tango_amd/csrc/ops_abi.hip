@@ -327,7 +327,17 @@ int tango_op_sched_step(float* latents, const float* model_out_nchw, const float
   p.lat = latents; p.eps = eps; p.xin = xin; p.xin_ld = 8; p.noise = noise; p.coef = dcoef; p.step_ptr = dstep;
   p.B = B; p.C = C; p.HW = HW; p.cfg = cfg; p.guidance = guidance; p.pred_type = pred_type; p.rule = rule; p.clip = clip;
   p.clip_range = clip_range; p.seed = 0; p.sample_offset = 0;
-  TANGO_TRY(launch_sched_step(DT_F32, p, s));
+  SchedParams* dp = (SchedParams*)sc.get(sizeof(SchedParams));
+  if (!dp) TANGO_FAIL("op_sched_step: alloc");
+  TANGO_HIP(hipMemcpyAsync(dp, &p, sizeof(SchedParams), hipMemcpyHostToDevice, s));
+  TANGO_TRY(launch_sched_step(DT_F32, dp, B * HW, s));
+  TANGO_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int tango_op_philox_normal(float* out, int B, int C, int HW, int step, uint64_t seed, int sample_offset, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  TANGO_TRY(launch_philox_normal(out, B, C, HW, step, seed, sample_offset, s));
   TANGO_HIP(hipStreamSynchronize(s));
   return 0;
 }

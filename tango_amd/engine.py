@@ -33,6 +33,15 @@ def normalize_unet_config(cfg: dict) -> dict:
             out[k] = cfg[k]
     if isinstance(out["attention_head_dim"], int):
         out["attention_head_dim"] = [out["attention_head_dim"]] * len(out["block_out_channels"])
+    # the engine derives the up path from the down path (unet_2d_condition.py:330-375 builds them independently):
+    # refuse configurations where up_block_types is not the mirror image instead of silently assuming it
+    down, up = list(out["down_block_types"]), list(out["up_block_types"])
+    known_d, known_u = {"CrossAttnDownBlock2D", "DownBlock2D"}, {"CrossAttnUpBlock2D", "UpBlock2D"}
+    if set(down) - known_d or set(up) - known_u:
+        raise ValueError("unsupported UNet block types %s / %s" % (down, up))
+    mirror = ["CrossAttnUpBlock2D" if d == "CrossAttnDownBlock2D" else "UpBlock2D" for d in reversed(down)]
+    if up != mirror or len(down) != len(out["block_out_channels"]):
+        raise ValueError("up_block_types %s must mirror down_block_types %s" % (up, down))
     return out
 
 

@@ -52,19 +52,34 @@ class AudioDiffusion:
         self.tokenizer = tokenizer
         self.bucket_text_len = bucket_text_len
         self.use_graph = True
-        self.seed = 0
+        self.seed = None          # None: every call draws its Philox key from torch's default generator (torch.manual_seed rules)
         self._calls = 0
+        self._text_sd = None      # `text_encoder.*` tensors of pytorch_model_main.bin, applied when the encoder exists
 
     # ---- state dict --------------------------------------------------------------------------
     def load_state_dict(self, sd, strict=True):
         """pytorch_model_main.bin: `unet.*` goes to the engine, `text_encoder.*` to the torch T5."""
         missing = self.engine.load_state_dict(sd, strict=strict)
         self.engine.finalize()
+        # The reference loads the checkpoint's text encoder through the same call (tango.py:28 -> nn.Module.load_state_dict,
+        # strict): checkpoints trained with freeze_text_encoder=False carry tuned T5 weights.  The encoder may not exist yet
+        # (it is built lazily), so the sub-dict is kept and applied by _ensure_text().
+        te = {k[len("text_encoder."):]: v for k, v in sd.items() if k.startswith("text_encoder.")}
+        self._text_sd = te or None
         if self.text_encoder is not None:
-            te = {k[len("text_encoder."):]: v for k, v in sd.items() if k.startswith("text_encoder.")}
-            if te:
-                self.text_encoder.load_state_dict(te, strict=False)
+            self._apply_text_sd()
         return missing
+
+    def _apply_text_sd(self):
+        if self._text_sd is None:
+            return
+        res = self.text_encoder.load_state_dict(self._text_sd, strict=False)
+        # `shared.weight` and `encoder.embed_tokens.weight` are one tied tensor: either name alone is complete
+        tied = {"shared.weight", "encoder.embed_tokens.weight"}
+        miss = [k for k in res.missing_keys if not (k in tied and tied & set(self._text_sd))]
+        if miss or res.unexpected_keys:
+            raise RuntimeError("text_encoder state_dict mismatch: missing %s unexpected %s" % (miss[:4], list(res.unexpected_keys)[:4]))
+        self._text_sd = None
 
     def eval(self):
         return self
@@ -78,6 +93,7 @@ class AudioDiffusion:
             from transformers import AutoTokenizer, T5EncoderModel   # models.py:98-100
             self.tokenizer = AutoTokenizer.from_pretrained(self.text_encoder_name)
             self.text_encoder = T5EncoderModel.from_pretrained(self.text_encoder_name).to(self.device).eval()
+        self._apply_text_sd()
 
     def encode_text(self, prompt: List[str]):
         """models.py:129-147"""
@@ -148,7 +164,9 @@ class AudioDiffusion:
         pe, pm = self._pad_text(prompt_embeds.to(self.device), boolean_prompt_mask.to(self.device))
         c = inference_scheduler.config
         if seed is None:
-            seed = (self.seed << 20) + self._calls
+            # the reference draws step noise from torch's global generator (randn_tensor in scheduler.step): derive the
+            # Philox key from that generator, so torch.manual_seed() fixes the whole trajectory and calls differ
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.seed is None else (int(self.seed) << 20) + self._calls
         self._calls += 1
         self.engine.denoise(latents, pe, pm, timesteps.cpu().numpy(), inference_scheduler.coef_table(), guidance_scale,
                             prediction_type=c.prediction_type, rule=inference_scheduler.rule, clip_sample=c.clip_sample,

@@ -16,7 +16,10 @@ _CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs"
 
 
 class Tango:
-    def __init__(self, name="declare-lab/tango", device="cuda:0", dtype="fp16", scheduler_config=None):
+    def __init__(self, name="declare-lab/tango", device="cuda:0", dtype="fp16", scheduler_config=None, text_encoder=None,
+                 tokenizer=None):
+        """`text_encoder` / `tokenizer` (optional): already-built T5EncoderModel / tokenizer, e.g. from a local directory
+        on a box without hub access; the checkpoint's `text_encoder.*` tensors are loaded into it like the reference does."""
         if os.path.isdir(name):
             path = name
         else:
@@ -31,7 +34,7 @@ class Tango:
             base = os.path.basename(cfg_path) if cfg_path else "diffusion_model_config.json"
             cfg_path = os.path.join(_CONFIG_DIR, base)
         main_config = dict(main_config, unet_model_config_path=cfg_path)
-        self.model = AudioDiffusion(**main_config, dtype=dtype, device=device)
+        self.model = AudioDiffusion(**main_config, dtype=dtype, device=device, text_encoder=text_encoder, tokenizer=tokenizer)
         vae_weights = torch.load("{}/pytorch_model_vae.bin".format(path), map_location="cpu")
         main_weights = torch.load("{}/pytorch_model_main.bin".format(path), map_location="cpu")
         self.vae.load_state_dict(vae_weights)
