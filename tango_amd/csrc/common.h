@@ -34,6 +34,7 @@ void set_error(const std::string& msg);
     if (_e != hipSuccess) {                                                                    \
       ::tango::set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " at " +   \
                          __FILE__ + ":" + std::to_string(__LINE__));                           \
+      (void)hipGetLastError(); /* reset the sticky error: it must not resurface in an unrelated later call */ \
       return -1;                                                                               \
     }                                                                                          \
   } while (0)
@@ -135,6 +136,8 @@ struct GemmParams {
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s);
 bool conv_halo_ok(int dtype, const GemmParams& p);
 int launch_conv_halo(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s);
+bool gemm_dma_ok(int dtype, const GemmParams& p);
+int launch_gemm_dma(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s);
 int gemm_init();   // process-wide one-time setup (zero page); call before any launch and outside stream capture
 // split-K factor the launcher wants for this problem (1 = none); caller provides ws = splitk*M*N floats
 int gemm_pick_splitk(int dtype, const GemmParams& p);

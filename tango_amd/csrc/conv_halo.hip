@@ -28,7 +28,17 @@ static constexpr int HALO_MAX_ROWS = 400;   // halo pixels per tile the LDS budg
 static constexpr int HALO_NA = 7;           // halo DMA pieces per wave per channel chunk (8 waves x 7 x 8 rows >= 400)
 
 // ABL = true compiles the ablation hooks in (TANGO_HALO_ABL, tools/halo_ablation.sh); the product instantiation has none.
-template <typename T, int BN, bool ABL>
+// PP = true selects the "ping-pong" main loop (round 2): the two 4-wave halves of the workgroup (waves w and w + 4 share
+// a SIMD) run HALF AN ITEM OUT OF PHASE.  Every (chunk, tap) item is two phases (64-byte k-groups), every phase is
+//   [ds_read the 9 fragments] s_barrier [20 MFMAs] s_barrier
+// and half B executes one extra barrier up front, so while one half of a SIMD's waves multiplies, the other half has its
+// LDS reads (and the DMA issue) in flight: the lock-step structure measured 45 % MFMA-busy inside the loop with the LDS
+// read latency exposed once per barrier (ablation: 117 of 553 us), here it hides behind the partner's MFMAs.
+// LDS-DMA protocol (3 weight stages, 2 halo buffers as before): the DMAs of item i+2 are issued at the START of the MFMA
+// part of phase (i, 0) -- by then every wave has retired its reads of item i-1 (whose stage is being refilled): the last
+// ones are half B's phase-(i-1, 1) reads, consumed by its MFMAs one barrier ago --, and each wave waits for its own
+// item-(i+1) DMAs in the read part of phase (i, 1), i.e. at least one barrier before the first read of item i+1.
+template <typename T, int BN, bool ABL, bool PP = false>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GemmParams p, const unsigned char* zero_page, const int SR,
                                                            const int nseg, const int abytes, const int abl_arg, const int staged) {
   const int abl = ABL ? abl_arg : 0;
@@ -138,6 +148,70 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GemmParams p, c
 
   const int NC = p.Cin / BK;
 
+  if constexpr (PP) {
+    const int half = wave >> 2;                       // 0: leading half, 1: trails by one slot
+    // prologue: halo of chunk 0, weight items 0 and 1; item 0 (and the halo) must have landed before the first read
+#pragma unroll
+    for (int t = 0; t < HALO_NA; ++t) issue_a(t, 0, 0);
+    issue_w(0, 0, 0);
+    issue_w(1, 0, 1);
+    wait_vmcnt_upto8(my_w);                           // leaves only item 1 in flight
+    pp_barrier();
+    if (half) pp_barrier();                           // the stagger: half B starts one slot late
+    int st = 0;
+    for (int cc = 0; cc < NC; ++cc) {
+      const unsigned char* Ah = As + (cc & 1) * abytes;
+      const bool more_c = cc + 1 < NC;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const unsigned char* Wst = Ws + st * WST;
+        const int toff = (tap / 3) * HW2 + (tap % 3);
+        int hb[TM];
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+          hb[b] = h00[b];
+          asm volatile("" : "+v"(hb[b]));
+        }
+        const bool has2 = (tap + 2 < 9) || more_c;    // item i+2 exists
+        const bool has1 = (tap + 1 < 9) || more_c;    // item i+1 exists
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          // ---- read part ----
+          u32x4 wf[TN], xf[TM];
+#pragma unroll
+          for (int a = 0; a < TN; ++a) wf[a] = *(const u32x4*)(Wst + wrow + a * 16 * BKB + wkoff[ks]);
+#pragma unroll
+          for (int b = 0; b < TM; ++b) {
+            const int h = hb[b] + toff;
+            xf[b] = *(const u32x4*)(Ah + h * BKB + (((ks * 4 + kg) ^ (h & 7)) << 4));
+          }
+          if (ks == 1) {
+            // item i+1 (issued one item ago) must have landed before anybody reads it; item i+2's DMAs (issued in phase 0
+            // of this item, AFTER an optional halo piece) may stay in flight
+            if (has1) wait_vmcnt_upto8(has2 ? my_w : 0);
+          }
+          pp_barrier();
+          // ---- multiply part ----
+          if (ks == 0) {
+            if (more_c && tap < HALO_NA) issue_a(tap, cc + 1, (cc + 1) & 1);
+            const int t2 = tap + 2;
+            const int st2 = st == 0 ? 2 : st - 1;     // (st + 2) % 3
+            if (t2 < 9) issue_w(t2, cc, st2);
+            else if (more_c) issue_w(t2 - 9, cc + 1, st2);
+          }
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b) Mma<T>::run(acc[a][b], wf[a], xf[b]);
+          __builtin_amdgcn_s_setprio(0);
+          pp_barrier();
+        }
+        st = st == 2 ? 0 : st + 1;
+      }
+    }
+    if (!half) pp_barrier();
+  } else {
   // prologue: halo of chunk 0, weight items 0 and 1
   if (!(abl & 32)) {
 #pragma unroll
@@ -208,6 +282,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GemmParams p, c
       st = st == 2 ? 0 : st + 1;
     }
   }
+  }
   if ((abl & 16) && acc[0][0][0] == 0.f) return;
   if (staged) {
     __syncthreads();   // every wave is past its last fragment read: the halo / weight LDS becomes the staging area
@@ -258,11 +333,14 @@ static int launch_halo_cfg(const GemmParams& p, const unsigned char* zero_page, 
   const int abytes = ((g.halo + 7) / 8) * 1024;
   const int lds = 2 * abytes + 3 * BN * 128;
   static const int abl = getenv("TANGO_HALO_ABL") ? atoi(getenv("TANGO_HALO_ABL")) : 0;   // ablation study switch
-  auto kfn = abl ? conv3x3_halo_kernel<T, BN, true> : conv3x3_halo_kernel<T, BN, false>;
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
+  const char* ppe = getenv("TANGO_CONV_PP");                                              // experiment switch: 0 = lock-step loop
+  const bool pp = !(ppe && ppe[0] == '0');
+  const int variant = abl ? 0 : (pp ? 2 : 1);
+  auto kfn = abl ? conv3x3_halo_kernel<T, BN, true, false> : (pp ? conv3x3_halo_kernel<T, BN, false, true> : conv3x3_halo_kernel<T, BN, false, false>);
+  static int attr_lds[3] = {0, 0, 0};
+  if (lds > attr_lds[variant]) {
     TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_lds = lds;
+    attr_lds[variant] = lds;
   }
   const int tiles = (p.M / 256) * (p.N / BN);
   static const bool no_stage = getenv("TANGO_NO_STAGED_EPILOGUE") != nullptr;   // experiment switch

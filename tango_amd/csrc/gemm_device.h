@@ -290,4 +290,23 @@ template <typename T> static inline bool epilogue_can_stage(const GemmParams& p)
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// counted vmcnt wait with a wave-uniform runtime count (the immediate must be a literal); counts above 8 wait for 8
+__device__ __forceinline__ void wait_vmcnt_upto8(const int n) {
+  if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+// raw workgroup barrier (no vmcnt drain: LDS-DMAs stay in flight across it) that the scheduler may not move code across
+__device__ __forceinline__ void pp_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 }  // namespace tango

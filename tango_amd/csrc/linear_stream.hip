@@ -328,6 +328,8 @@ bool linear_stream_ok(int dtype, const GemmParams& p) {
   else if (rowb == 1280) tn = 5;
   else return false;
   if (p.N % (16 * tn) != 0) return false;
+  // weight panel + per-wave output staging + constants must fit the 160-KB LDS (fp32 rows of 640 bytes do not)
+  if ((long)16 * tn * rowb + 8L * 16 * (16 * tn * esz + 16) + 2L * 16 * tn * 4 > 160 * 1024) return false;
   if (p.epi == EPI_GEGLU && (tn & 1)) return false;
   if (p.epi == EPI_VT && (p.vt_n0 % 16) != 0) return false;
   if ((p.ldo % 4) || (p.R && (p.ldr % 4))) return false;

@@ -2,12 +2,15 @@
 
 The path shards embarrassingly: every prompt's trajectory is independent (GroupNorm / LayerNorm /
 attention are per-sample; a prompt's CFG twin stays on its GPU), so there is NO per-step collective.
-One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI); exactly two collectives
-per batch: a broadcast of the text-encoder outputs from rank 0 (north-star: "RCCL broadcast of text
+One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI); per batch: one small header
+broadcast, a broadcast of the text-encoder outputs from rank 0 (north-star: "RCCL broadcast of text
 embeddings over xGMI only") and a gather of the int16 waveforms back to rank 0.  The reference has no
 inference-side parallelism (tango.py:54-60 is a Python loop over chunks) -- this replaces that loop.
+
+Step noise is keyed by (seed, GLOBAL sample index): rank 0 draws ONE seed per batch and broadcasts it in the
+header, so results do not depend on the number of ranks and no per-rank call counter can drift.
 """
-from typing import Callable, List, Optional, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -37,7 +40,8 @@ def shard_cfg_embeddings(prompt_embeds: torch.Tensor, mask: torch.Tensor, world:
 
 
 class DataParallelGenerator:
-    """compute(embeds_local, mask_local, sample_offset) -> np.int16 [b_local, n_samples]"""
+    """compute(embeds_local, mask_local, sample_offset, seed) -> int16 [b_local, n_samples]
+    (a torch tensor on `device` -- it is gathered without leaving the device -- or a numpy array)."""
 
     def __init__(self, compute: Callable, device: torch.device, group=None):
         self.compute = compute
@@ -56,40 +60,75 @@ class DataParallelGenerator:
         return t
 
     def generate(self, prompt_embeds: Optional[torch.Tensor], mask: Optional[torch.Tensor], guidance: float,
-                 n_samples: int) -> Optional[np.ndarray]:
+                 n_samples: int, seed: Optional[int] = None) -> Optional[np.ndarray]:
         """Rank 0 passes the global embeddings ([2B, L, d] when guidance > 1); other ranks pass None.
+        `seed`: rank 0's value is used (None: drawn from torch's default generator on rank 0).
         Returns the global int16 waveforms [B, n_samples] on rank 0, None elsewhere."""
         cfg_on = guidance > 1.0
-        hdr = torch.zeros(3, dtype=torch.int64, device=self.device)
+        hdr = torch.zeros(4, dtype=torch.int64, device=self.device)
         if self.rank == 0:
-            hdr = torch.tensor(list(prompt_embeds.shape), dtype=torch.int64, device=self.device)
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            hdr = torch.tensor(list(prompt_embeds.shape) + [int(seed)], dtype=torch.int64, device=self.device)
         if self.world > 1:
             dist.broadcast(hdr, src=0, group=self.group)
-        n2, L, d = [int(v) for v in hdr.tolist()]
+        n2, L, d, seed = [int(v) for v in hdr.tolist()]
         pe = self._bcast(prompt_embeds, (n2, L, d), torch.float32)
         pm = self._bcast(mask.to(torch.uint8) if mask is not None else None, (n2, L), torch.uint8)
         B = n2 // 2 if cfg_on else n2
         pe_l, pm_l, lo = shard_cfg_embeddings(pe, pm.bool(), self.world, self.rank, cfg_on)
         b_local = pe_l.shape[0] // 2 if cfg_on else pe_l.shape[0]
+        wav = None
         if b_local > 0:
-            wav = np.asarray(self.compute(pe_l, pm_l, lo))
-            assert wav.dtype == np.int16 and wav.shape == (b_local, n_samples), (wav.dtype, wav.shape)
-        else:
-            wav = np.zeros((0, n_samples), np.int16)
+            wav = self.compute(pe_l, pm_l, lo, seed)
+            if isinstance(wav, np.ndarray):
+                wav = torch.from_numpy(wav)
+            assert wav.dtype == torch.int16 and tuple(wav.shape) == (b_local, n_samples), (wav.dtype, tuple(wav.shape))
         if self.world == 1:
-            return wav
+            return wav.cpu().numpy() if wav is not None else np.zeros((0, n_samples), np.int16)
         bmax = (B + self.world - 1) // self.world
         buf = torch.zeros((bmax, n_samples), dtype=torch.int16, device=self.device)
-        buf[:b_local] = torch.from_numpy(wav).to(self.device)
+        if wav is not None:
+            buf[:b_local] = wav.to(self.device)
         # neither RCCL nor gloo has an int16 datatype: ship the waveform bytes
         raw = buf.view(torch.uint8)
         outs8 = [torch.empty_like(raw) for _ in range(self.world)] if self.rank == 0 else None
         dist.gather(raw, outs8, dst=0, group=self.group)
-        outs = [o.view(torch.int16) for o in outs8] if self.rank == 0 else None
         if self.rank != 0:
             return None
         parts: List[np.ndarray] = []
         for r in range(self.world):
             a, bnd = shard_bounds(B, self.world, r)
-            parts.append(outs[r][: bnd - a].cpu().numpy())
+            parts.append(outs8[r].view(torch.int16)[: bnd - a].cpu().numpy())
         return np.concatenate(parts, 0)
+
+
+def generate_for_batch_dp(prompts: Optional[Sequence[str]], encode: Callable, compute: Callable, n_samples: int, device,
+                          guidance: float = 3, samples: int = 1, batch_size: int = 8, group=None):
+    """Prompt-level data-parallel `generate_for_batch` (tango.py:51-64 is the loop this shards).
+
+    Every rank calls it; only rank 0's `prompts` are read (other ranks may pass None).  Per pass rank 0 runs the text
+    encoder on `batch_size * world` prompts (`encode(batch, samples, guidance) -> (embeds [n2, L, d], bool mask)`, the
+    serial stage SURVEY.md 8e names), the embeddings are broadcast, each rank generates its contiguous shard
+    (`compute(embeds_local, mask_local, sample_offset, seed) -> int16 [b_local, n_samples]`) and rank 0 gathers.
+    Returns on rank 0 what `Tango.generate_for_batch` returns (list of waveforms, grouped per prompt when samples > 1);
+    None on the other ranks."""
+    dp = DataParallelGenerator(compute, torch.device(device), group)
+    n = torch.tensor([len(prompts) if dp.rank == 0 else 0], dtype=torch.int64, device=dp.device)
+    if dp.world > 1:
+        dist.broadcast(n, src=0, group=group)
+    n = int(n.item())
+    per_pass = batch_size * dp.world
+    outputs: List[np.ndarray] = []
+    for k in range(0, n, per_pass):
+        pe = pm = None
+        if dp.rank == 0:
+            pe, pm = encode(list(prompts[k:k + per_pass]), samples, guidance)
+        wav = dp.generate(pe, pm, guidance, n_samples)
+        if dp.rank == 0:
+            outputs += [w for w in wav]
+    if dp.rank != 0:
+        return None
+    if samples == 1:
+        return outputs
+    return [outputs[i:i + samples] for i in range(0, len(outputs), samples)]

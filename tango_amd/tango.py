@@ -80,6 +80,29 @@ class Tango:
             return outputs
         return list(self.chunks(outputs, samples))
 
+    def generate_for_batch_dp(self, prompts, steps=100, guidance=3, samples=1, batch_size=8, group=None):
+        """Data-parallel `generate_for_batch` over the ranks of the default (or given) torch.distributed group: one
+        process per GPU, each holding a full `Tango`.  Every rank makes this call; rank 0's `prompts` are used, the text
+        encoder runs on rank 0 only, embeddings travel by one RCCL broadcast per pass of `batch_size * world` prompts,
+        int16 waveforms come back by one gather.  Returns the `generate_for_batch` result on rank 0, None elsewhere."""
+        from .parallel import generate_for_batch_dp
+
+        def encode(batch, n_per_prompt, g):
+            if g > 1.0:
+                pe, pm = self.model.encode_text_classifier_free(batch, n_per_prompt)
+            else:
+                pe, pm = self.model.encode_text(batch)
+                pe, pm = pe.repeat_interleave(n_per_prompt, 0), pm.repeat_interleave(n_per_prompt, 0)
+            return pe.float(), pm
+
+        def compute(pe, pm, offset, seed):
+            latents = self.model.inference_from_embeddings(pe, pm, self.scheduler, steps, guidance, seed=seed, sample_offset=offset)
+            return self.vae.engine.vocode(self.vae.decode_first_stage(latents))      # int16 stays on the device
+
+        with torch.no_grad():
+            return generate_for_batch_dp(prompts, encode, compute, self.vae.engine.vocoder_samples(1024), self.model.device,
+                                         guidance=guidance, samples=samples, batch_size=batch_size, group=group)
+
     def generate_from_embeddings(self, prompt_embeds, boolean_prompt_mask, steps=100, guidance=3, **kw):
         """Same three calls given the text-encoder outputs (benchmarks / data-parallel workers)."""
         with torch.no_grad():

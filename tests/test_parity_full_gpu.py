@@ -108,8 +108,9 @@ def test_config1_full_size_fp32():
     assert snr_db(wav, r["wav"]) >= 40.0
 
 
-# floors: measured values are printed (and recorded in DESIGN.md section 3); the floors leave ~6 dB of margin
-@pytest.mark.parametrize("dtype,lat_tol,mel_floor,wav_floor", [("fp16", 5e-2, 50.0, 25.0), ("bf16", 4e-1, 32.0, 8.0)])
+# measured on MI355X (round 2, recorded in DESIGN.md section 3): fp16 4.6e-3 / 70.5 dB / 47.7 dB, bf16 4.0e-2 / 52.3 dB / 29.7 dB;
+# the asserted floors leave ~8 dB (4x on the latents) of margin
+@pytest.mark.parametrize("dtype,lat_tol,mel_floor,wav_floor", [("fp16", 2e-2, 62.0, 39.0), ("bf16", 1.6e-1, 44.0, 21.0)])
 def test_config1_reduced_precision_ladder(dtype, lat_tol, mel_floor, wav_floor):
     r = config1_reference()
     lat, mel, wav, _ = run_config1(dtype)
@@ -173,8 +174,10 @@ def test_philox_noise_statistics(lib):
 
 
 def test_denoise_shard_invariance_on_device_noise():
-    """Two shards (sample_offset 0 and 2) of a 4-prompt batch reproduce the unsharded run bit for bit with the device
-    Philox noise: results do not depend on how many GPUs the prompts are split over."""
+    """Two shards (sample_offset 0 and 2) of a 4-prompt batch reproduce the unsharded run with the device Philox noise:
+    results do not depend on how many GPUs the prompts are split over.  The NOISE is bit-identical
+    (test_philox_noise_statistics); the latents agree to fp32 rounding only, because the GEMM tiling / split-K policy --
+    hence the summation order -- depends on the UNet batch."""
     cfg = O.UNET_CONFIG_TINY
     e = Engine(unet=cfg, dtype="fp32")
     e.load_synthetic(1234)
@@ -199,12 +202,14 @@ def test_denoise_shard_invariance_on_device_noise():
 
     full = run(0, 4)
     parts = torch.cat([run(0, 2), run(2, 4)])
-    assert torch.equal(full, parts)
+    d = (full - parts).abs().max().item()
+    print("shard invariance: max abs difference between the 4-prompt run and the 2+2 sharded run %.3e" % d)
+    assert d <= 2e-5 * full.abs().max().item()
     assert not torch.equal(full[0], full[1])
     other = lat0.clone().cuda()
     e.denoise(other, torch.cat([unc, cond]).cuda(), torch.cat([mask_u, mask_c]).cuda(), sch.timesteps.numpy(), sch.coef_table(), 3.0,
               noise=None, seed=4243, sample_offset=0)
-    assert not torch.equal(other.cpu(), full), "a different seed must give different step noise"
+    assert (other.cpu() - full).abs().max().item() > 1e-2, "a different seed must give different step noise"
 
 
 def test_weight_reload_invalidates_time_embedding_cache():

@@ -1,10 +1,12 @@
 #!/bin/bash
-# one gpurun call of round 2: micro-benchmarks, new parity / determinism tests, per-op profile, short bench
+# gpurun call 2 of round 2: correctness of the ping-pong loops, race characterisation, A/B per-op profiles
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r2; mkdir -p $O
-timeout 120 build/mfma_war_repro 2000 512 > $O/mfma_war_repro.txt 2>&1; echo "repro rc=$?"
-timeout 120 build/fill_bench > $O/fill_bench.txt 2>&1; echo "fill rc=$?"
-timeout 1000 python -m pytest tests/test_parity_full_gpu.py tests/test_determinism_gpu.py tests/test_string_ckpt_gpu.py -m gpu -q -s --maxfail=25 > $O/newtests.log 2>&1; echo "tests rc=$?"
-timeout 300 python tools/profile_unet_ops.py --out $O/unet_ops_v21.txt > /dev/null 2>&1; echo "prof rc=$?"
-timeout 300 python bench.py --steps 1 --warmup 1 --denoise-steps 20 --no-cpu-baseline > $O/bench_v21.json 2> $O/bench_v21.err; echo "bench rc=$?"
-tail -3 $O/mfma_war_repro.txt; tail -5 $O/newtests.log; head -3 $O/unet_ops_v21.txt; cat $O/bench_v21.json | cut -c1-400
+timeout 600 python -m pytest tests/test_ops_gpu.py -m gpu -q -x -k "conv2d or linear" > $O/ops_pp.log 2>&1; echo "ops rc=$?"; tail -2 $O/ops_pp.log
+TANGO_STRESS_REPS=30 timeout 600 python -m pytest tests/test_determinism_gpu.py -m gpu -q -k "conv3x3 or linear_repeat or large_mean" > $O/det_pp.log 2>&1; echo "det rc=$?"; tail -4 $O/det_pp.log
+timeout 300 python -m pytest tests/test_string_ckpt_gpu.py "tests/test_parity_full_gpu.py::test_denoise_shard_invariance_on_device_noise" -m gpu -q -s > $O/str.log 2>&1; echo "str rc=$?"; tail -4 $O/str.log
+REPS=300 DTYPE=bf16 timeout 200 python tools/diag_stream_race.py > $O/race_bf16.txt 2>&1; tail -3 $O/race_bf16.txt
+REPS=300 DTYPE=bf16 TANGO_NO_STAGED_EPILOGUE=1 timeout 200 python tools/diag_stream_race.py > $O/race_bf16_nostage.txt 2>&1; tail -2 $O/race_bf16_nostage.txt
+REPS=200 DTYPE=fp16 timeout 200 python tools/diag_stream_race.py > $O/race_fp16.txt 2>&1; tail -2 $O/race_fp16.txt
+timeout 200 python tools/profile_unet_ops.py --out $O/unet_ops_pp.txt > /dev/null 2>&1; echo "prof rc=$?"; head -1 $O/unet_ops_pp.txt
+TANGO_CONV_PP=0 TANGO_GEMM_PP=0 timeout 200 python tools/profile_unet_ops.py --out $O/unet_ops_nopp.txt > /dev/null 2>&1; head -1 $O/unet_ops_nopp.txt
