@@ -43,6 +43,25 @@ template <> struct AMma<bf16> {
   }
 };
 
+// max over the four lanes {l, l^16, l^32, l^48} that hold one query's kv slices, WITHOUT the LDS crossbar:
+// v_permlane32_swap / v_permlane16_swap exchange 32- / 16-lane halves between two registers (2 VALU + 1 max per step,
+// no ds_bpermute round trip in the softmax dependency chain).  The max is taken in inline asm: (a) hipcc (ROCm 7.2)
+// folds fmaxf(r[0], r[1]) of the swap builtin's two results to r[0] -- it treats them as equal --, (b) it would put a
+// canonicalising v_max x, x in front of each operand.
+__device__ __forceinline__ float asm_max(float a, float b) {
+  float m;
+  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+  return m;
+}
+__device__ __forceinline__ float quad_max(float v) {
+  const unsigned a = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+  const float m = asm_max(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+  const unsigned c = __builtin_bit_cast(unsigned, m);
+  const auto q = __builtin_amdgcn_permlane16_swap(c, c, false, false);
+  return asm_max(__builtin_bit_cast(float, (unsigned)q[0]), __builtin_bit_cast(float, (unsigned)q[1]));
+}
+
 // NW waves per workgroup share one K / V^T tile stream: the L2 -> LDS fill per workgroup is fixed (the whole K and V of
 // the (batch, head)), so the fill bytes per MFMA flop scale with 1 / (NW * QB).
 template <typename T, int QB, bool MASKED, int NW, int MINW>
@@ -96,17 +115,35 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
   }
 
   // ---- staging: thread -> (row, 16-byte piece) of the K tile and of the V^T tile ----
+  // Addresses are a wave-uniform tile base (advanced per tile on the scalar unit) plus a per-thread 32-bit offset that
+  // is constant over the loop: no 64-bit VALU address arithmetic per tile (round 1: ~60 VALU of the ~250 per tile in a
+  // VALU-co-limited loop).  MASKED == false means Skv % 64 == 0 and ldvt >= Skv: every piece is in range, no tests.
   u32x4 kreg[NPASS], vreg[NPASS];
+  unsigned koff[NPASS], voff[NPASS];
+#pragma unroll
+  for (int i = 0; i < NPASS; ++i) {
+    const int id = tid + i * NTH;
+    const int row = id / PPR, pc = id % PPR;
+    koff[i] = (unsigned)row * (unsigned)(p.ldk * (int64_t)sizeof(T)) + pc * 16;
+    voff[i] = (unsigned)row * (unsigned)(p.ldvt * (int64_t)sizeof(T)) + pc * 16;
+  }
   auto load_tile = [&](int kv0) {
+    const unsigned char* Kt = (const unsigned char*)Kp + (int64_t)kv0 * p.ldk * (int64_t)sizeof(T);
+    const unsigned char* Vt = (const unsigned char*)Vp + (int64_t)kv0 * (int64_t)sizeof(T);
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
       const int id = tid + i * NTH;
       const int row = id / PPR, pc = id % PPR;
-      u32x4 kk = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
       if (NPIECE % NTH != 0 && id >= NPIECE) continue;
-      if (kv0 + row < p.Skv) kk = *(const u32x4*)((const unsigned char*)(Kp + (int64_t)(kv0 + row) * p.ldk) + pc * 16);
-      if (kv0 + pc * EPV < p.ldvt) vv = *(const u32x4*)((const unsigned char*)(Vp + (int64_t)row * p.ldvt + kv0) + pc * 16);
-      kreg[i] = kk; vreg[i] = vv;
+      if (MASKED) {
+        u32x4 kk = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
+        if (kv0 + row < p.Skv) kk = *(const u32x4*)(Kt + koff[i]);
+        if (kv0 + pc * EPV < p.ldvt) vv = *(const u32x4*)(Vt + voff[i]);
+        kreg[i] = kk; vreg[i] = vv;
+      } else {
+        kreg[i] = *(const u32x4*)(Kt + koff[i]);
+        vreg[i] = *(const u32x4*)(Vt + voff[i]);
+      }
     }
   };
   auto store_tile = [&](int st) {
@@ -188,22 +225,25 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
             sacc[qb][kb][r] = sv;
             mt = fmaxf(mt, sv);
           }
-        mt = fmaxf(mt, __shfl_xor(mt, 16));
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
-        mnew = fmaxf(mrow[qb], mt);
+        mnew = fmaxf(mrow[qb], quad_max(mt));
       } else {
         // unmasked: max(sc2 * s) == sc2 * max(s) (sc2 > 0), so the scale is applied once to the maximum and otherwise
-        // rides along in the exponent's FMA -- 16 multiplies per query block and tile less on the VALU, which is the
-        // co-limiter of this kernel (34 v_exp + ~150 VALU vs 32 MFMA per tile)
+        // rides along in the exponent's FMA
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) mt = fmaxf(mt, sacc[qb][kb][r]);
-        mt = fmaxf(mt, __shfl_xor(mt, 16));
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
-        mnew = fmaxf(mrow[qb], mt * sc2);
+        mnew = fmaxf(mrow[qb], quad_max(mt) * sc2);
       }
-      const float alpha = __builtin_amdgcn_exp2f(mrow[qb] - mnew);
+      // lazy rescale: after the first few tiles the running maximum rarely moves; when it moved for NO query of this wave
+      // the O / l rescale (alpha == 1 exactly) and its exponential are skipped -- same values, 32 multiplies fewer
+      if (__builtin_amdgcn_ballot_w64(mnew > mrow[qb]) != 0ull) {
+        const float alpha = __builtin_amdgcn_exp2f(mrow[qb] - mnew);
+        lrow[qb] *= alpha;
+        mrow[qb] = mnew;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) oacc[qb][db] *= alpha;
+      }
       float rs = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
@@ -214,12 +254,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
           sacc[qb][kb][r] = pv;
           rs += pv;
         }
-      rs += __shfl_xor(rs, 16);
-      rs += __shfl_xor(rs, 32);
-      lrow[qb] = lrow[qb] * alpha + rs;
-      mrow[qb] = mnew;
-#pragma unroll
-      for (int db = 0; db < 4; ++db) oacc[qb][db] *= alpha;
+      lrow[qb] += rs;          // per-lane partial of the row sum: the four kv slices of a query are added once, after the loop
     }
 
     // ---- O^T += V^T P^T ----
@@ -272,7 +307,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int q = qbase + qb * 16 + l15;
-    const float inv = 1.0f / lrow[qb];
+    float lsum = lrow[qb];
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    const float inv = 1.0f / lsum;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       T e[4];

@@ -50,7 +50,9 @@ template <typename T> __device__ __forceinline__ void frag_stats(const u32x4& v,
 // KS = K*sizeof(T)/64 k-steps per row, TN = 16-column tiles per panel (BN = 16*TN); ring of R = 10 k-steps
 // LN (folded LayerNorm) is a template parameter: a wave-uniform runtime test in the micro-step loop is not free
 // (the halo conv gained 7-9 % when its ablation tests were compiled out).
-template <typename T, int KS, int TN, bool LN>
+// DBG != 0: diagnostic builds for the race hunt (tools/diag_stream_race.py, TANGO_STREAM_DBG): extra waits at the top of every
+// 16-row epilogue pass -- 1: vmcnt(0) + lgkmcnt(0) + nops, 2: lgkmcnt(0) + nops, 3: nops only
+template <typename T, int KS, int TN, bool LN, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) {
   constexpr int R = (TN > 5) ? 5 : 10;         // ring depth in k-steps (register budget: acc 8*TN + ring 8*R)
   constexpr int TM = 2;
@@ -225,6 +227,9 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
     }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
+      if (DBG == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");
+      if (DBG == 2) asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");
+      if (DBG == 3) asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
 #pragma unroll
       for (int a = 0; a < TN; ++a) {
         if (p.epi == EPI_GEGLU && (a & 1)) continue;
@@ -286,12 +291,12 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
   }
 }
 
-template <typename T, int KS, int TN, bool LN>
+template <typename T, int KS, int TN, bool LN, int DBG = 0>
 static int stream_launch(const GemmParams& p, hipStream_t s) {
   constexpr int BN = TN * 16;
   constexpr int LDS = BN * KS * 64 + 8 * 16 * (BN * (int)sizeof(T) + 16) + 2 * BN * 4;   // weight panel + per-wave output staging + constants
   static bool attr_set = false;
-  auto kfn = lin_stream_kernel<T, KS, TN, LN>;
+  auto kfn = lin_stream_kernel<T, KS, TN, LN, DBG>;
   if (!attr_set) {
     TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
@@ -340,7 +345,16 @@ template <typename T>
 static int stream_t(const GemmParams& p, hipStream_t s) {
   const int rowb = p.K * (int)sizeof(T);
   if (rowb == 640) return p.ln_fold ? stream_launch<T, 10, 10, true>(p, s) : stream_launch<T, 10, 10, false>(p, s);
-  if (rowb == 1280) return p.ln_fold ? stream_launch<T, 20, 5, true>(p, s) : stream_launch<T, 20, 5, false>(p, s);
+  if (rowb == 1280) {
+    if constexpr (sizeof(T) == 2 && TypeTag<T>::dt == DT_BF16) {   // diagnostic variants exist for the failing instantiation only
+      const char* e = getenv("TANGO_STREAM_DBG");
+      const int dbg = e ? atoi(e) : 0;
+      if (p.ln_fold && dbg == 1) return stream_launch<T, 20, 5, true, 1>(p, s);
+      if (p.ln_fold && dbg == 2) return stream_launch<T, 20, 5, true, 2>(p, s);
+      if (p.ln_fold && dbg == 3) return stream_launch<T, 20, 5, true, 3>(p, s);
+    }
+    return p.ln_fold ? stream_launch<T, 20, 5, true>(p, s) : stream_launch<T, 20, 5, false>(p, s);
+  }
   TANGO_FAIL("linear_stream: unsupported K");
 }
 
