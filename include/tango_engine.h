@@ -82,6 +82,12 @@ typedef struct tango_config {
   int32_t voc_n_resblocks;                    /* len(resblock_kernel_sizes) == 3 */
   int32_t voc_res_kernels[4];
   int32_t voc_res_dilations[4][4];            /* [kernel idx][pair idx]; 0-terminated rows */
+  /* FLAN-T5 encoder (transformers T5EncoderModel; reference call sites models.py:98-100,129-147,266-305).  Built when
+   * t5_layers > 0; weights are the `text_encoder.*` tensors of pytorch_model_main.bin (HF key names). */
+  int32_t t5_layers;                          /* num_layers (24 for flan-t5-large / -xl) */
+  int32_t t5_d_model, t5_d_kv, t5_heads, t5_d_ff, t5_vocab;   /* d_kv must be 64 */
+  int32_t t5_rel_buckets, t5_rel_max_distance;                /* relative_attention_num_buckets (32), _max_distance (128) */
+  float t5_eps;                               /* layer_norm_epsilon (1e-6) */
 } tango_config_t;
 
 typedef struct tango_denoise_args {
@@ -131,6 +137,11 @@ int tango_engine_vae_decode(tango_engine_t* h, const float* latents, float* mel,
 /* mel [B,1,T,num_mels] fp32 -> int16 [B, samples]; returns samples per item via *n_samples (may be NULL) */
 int tango_engine_vocode(tango_engine_t* h, const float* mel, int16_t* wav, int batch, int mel_frames, int* n_samples, void* stream);
 int tango_engine_vocoder_samples(tango_engine_t* h, int mel_frames);
+
+/* T5 encoder forward (replaces text_encoder(input_ids, attention_mask)[0], models.py:139-141,279-281,291-293):
+ * input_ids int64 [B, L] (device), attention_mask uint8 [B, L] (device, 1 = token, may be NULL), out fp32 [B, L, d_model] */
+int tango_engine_encode_text(tango_engine_t* h, const int64_t* input_ids, const uint8_t* attention_mask, float* out, int batch,
+                             int text_len, void* stream);
 
 /* timing of the last denoise call's kernels, measured with HIP events on the launch stream */
 int tango_engine_last_denoise_ms(tango_engine_t* h, float* total_ms, float* per_step_ms);

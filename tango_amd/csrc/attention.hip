@@ -64,8 +64,10 @@ __device__ __forceinline__ float quad_max(float v) {
 
 // NW waves per workgroup share one K / V^T tile stream: the L2 -> LDS fill per workgroup is fixed (the whole K and V of
 // the (batch, head)), so the fill bytes per MFMA flop scale with 1 / (NW * QB).
-template <typename T, int QB, bool MASKED, int NW, int MINW>
+// PB: additive per-(head, query, key) bias shared by the batch (T5 relative position bias); implies MASKED.
+template <typename T, int QB, bool MASKED, int NW, int MINW, bool PB = false>
 __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p) {
+  static_assert(!PB || MASKED, "position bias rides on the masked path");
   constexpr int NTH = NW * 64;
   constexpr int EPV = 16 / (int)sizeof(T);
   constexpr int D = 64, KVT = 64;
@@ -221,7 +223,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float sv = sacc[qb][kb][r] * sc2 + bv[MASKED ? kb : 0][r];
+            float sv = sacc[qb][kb][r] * sc2 + bv[MASKED ? kb : 0][r];
+            if (PB) {
+              const int q = qbase + qb * 16 + l15, kv = kv0 + kb * 16 + g * 4 + r;
+              if (q < p.Sq && kv < p.Skv) sv += p.pos_bias[((int64_t)h * p.Sq + q) * p.Skv + kv] * LOG2E;
+            }
             sacc[qb][kb][r] = sv;
             mt = fmaxf(mt, sv);
           }
@@ -338,6 +344,12 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
       (p.ldo * (int64_t)sizeof(T)) % 8)
     TANGO_FAIL("attention: ld alignment");
   const bool masked = p.bias != nullptr || (p.Skv % 64) != 0;
+  if (p.pos_bias) {   // text-encoder self-attention (short sequences): one query block per wave
+    dim3 grid((unsigned)((p.Sq + 63) / 64), (unsigned)p.heads, (unsigned)p.B);
+    hipLaunchKernelGGL((attn_kernel<T, 1, true, 4, 3, true>), grid, dim3(256), 0, s, p);
+    TANGO_HIP(hipGetLastError());
+    return 0;
+  }
   if (p.Sq > 512) {
     // 4 waves x 32 query rows per workgroup at 3 workgroups/CU.  Wider workgroups (6 or 8 waves sharing one K/V tile
     // stream, i.e. 1.5-2x fewer L2->LDS bytes per flop) were measured in round 1: 8 waves 10.5 ms vs 9.2 ms per step

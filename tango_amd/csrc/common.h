@@ -55,9 +55,36 @@ template <typename T> __device__ __forceinline__ T from_f(float v) { return (T)v
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// "gelu_new" of T5 v1.1 / FLAN-T5 (transformers activations.py NewGELUActivation): tanh approximation
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+// Branch-free erf for 16-bit outputs: Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 (fp16 / bf16 epsilon is 1e-3 / 8e-3).
+// libm's erff is two branchy ~25-op paths that a wave executes BOTH of; in the K = 320 GEGLU epilogue that VALU time equals
+// the MFMA time of the whole tile (1280 flops per gated output).  ~12 VALU + v_rcp + v_exp here.
+__device__ __forceinline__ float erf_as_f(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
+  const float r = __builtin_fmaf(-p, e, 1.0f);
+  return __builtin_copysignf(r, x);
+}
+template <typename T> __device__ __forceinline__ float gelu_erf_t(float x) {
+  if constexpr (sizeof(T) == 4) return gelu_erf_f(x);          // fp32 engine: libm erff (parity path)
+  else return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f));
+}
+// gate activation of the fused gated-linear-unit epilogue: exact-erf GELU (diffusers GEGLU) or tanh GELU (T5 gated-gelu)
+template <typename T> __device__ __forceinline__ float glu_gate_f(float x, int tanh_form) {
+  return tanh_form ? gelu_tanh_f(x) : gelu_erf_t<T>(x);
+}
 
 // activation codes shared by prologues / epilogues
-enum Act : int { ACT_NONE = 0, ACT_SILU = 1, ACT_LRELU = 2, ACT_GELU = 3, ACT_TANH = 4 };
+enum Act : int { ACT_NONE = 0, ACT_SILU = 1, ACT_LRELU = 2, ACT_GELU = 3, ACT_TANH = 4, ACT_GELU_TANH = 5 };
 
 __device__ __forceinline__ float apply_act(float x, int act, float slope) {
   switch (act) {
@@ -65,6 +92,7 @@ __device__ __forceinline__ float apply_act(float x, int act, float slope) {
     case ACT_LRELU: return x > 0.f ? x : x * slope;
     case ACT_GELU: return gelu_erf_f(x);
     case ACT_TANH: return tanhf(x);
+    case ACT_GELU_TANH: return gelu_tanh_f(x);
     default: return x;
   }
 }
@@ -110,6 +138,7 @@ struct GemmParams {
   int a_act = ACT_NONE;      // prologue on A
   float a_slope = 0.f;
   int epi = EPI_NONE;
+  int glu_tanh = 0;          // EPI_GEGLU gate activation: 0 exact-erf GELU (diffusers GEGLU), 1 tanh GELU (T5 gated-gelu)
   int e_act = ACT_NONE;      // epilogue activation (after bias, before residual)
   float e_slope = 0.f;
   float alpha = 1.f;
@@ -171,6 +200,7 @@ struct AttnParams {
   const void* vt; int64_t ldvt;   // V transposed: [B][heads][64][ldvt] (columns >= Skv must be zero / finite)
   void* o; int64_t ldo;
   const float* bias;              // [B][Skv] additive or null
+  const float* pos_bias = nullptr; // [heads][Sq][Skv] additive, shared by the batch (T5 relative position bias) or null
   int B, heads, Sq, Skv;
   float scale;
 };
@@ -222,6 +252,8 @@ int launch_linear_f32(const float* x, const float* W, const float* b, float* y, 
 
 // ---- weight packing (fp32 source in reference layout -> T engine layout) ----
 // generic strided permute-cast: dst[o][t][i] = src[o*so + t*st + i*si], dst row stride Kp (zero pad)
+// dst_row_off: >= 0 plain row offset; -1 GEGLU interleave of a [2*half][K] matrix (value rows then gate rows);
+// -2 / -3: the source holds ONLY the value / gate half ([half][K], O = half) of such a matrix (T5 wi_1 / wi_0)
 int launch_pack(int dtype, const float* src, void* dst, int O, int Tn, int I, int64_t so, int64_t st, int64_t si,
                 int64_t Kp, int64_t dst_row_off, hipStream_t s);
 int launch_fill_zero(void* p, size_t bytes, hipStream_t s);
@@ -229,5 +261,12 @@ int launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 int launch_pointwise_small(int dtype, const float* src, const float* W, const float* b, void* dst, int64_t ld, int B, int Cin,
                            int Cout, int HW, float scale, hipStream_t s);
 int launch_permute_geglu_bias(const float* src, float* dst, int n, hipStream_t s);
+// ---- text encoder (T5) helpers ----
+// rows out[r][:] = table[ids[r]][:] (fp32 table -> T)
+int launch_embed_gather(int dtype, const int64_t* ids, const float* table, void* out, int64_t ld, int rows, int D, int vocab, hipStream_t s);
+// T5LayerNorm (RMS norm, no mean subtraction, no bias): y = x * rsqrt(mean(x^2) + eps) * gamma; out_f32: write fp32 instead of T
+int launch_rmsnorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, int rows, int C, float eps, int out_f32, hipStream_t s);
+// pos_bias[h][i][j] = table[bucket[i][j]][h]   (table fp32 [num_buckets][heads], bucket int32 [L][L] from the host)
+int launch_t5_pos_bias(const float* table, const int* bucket, float* out, int heads, int L, hipStream_t s);
 
 }  // namespace tango

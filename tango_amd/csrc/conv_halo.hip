@@ -40,7 +40,8 @@ static constexpr int HALO_NA = 7;           // halo DMA pieces per wave per chan
 // item-(i+1) DMAs in the read part of phase (i, 1), i.e. at least one barrier before the first read of item i+1.
 template <typename T, int BN, bool ABL, bool PP = false>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GemmParams p, const unsigned char* zero_page, const int SR,
-                                                           const int nseg, const int abytes, const int abl_arg, const int staged) {
+                                                           const int nseg, const int abytes, const int abl_arg, const int staged,
+                                                           const int pp_mode) {
   const int abl = ABL ? abl_arg : 0;
   constexpr int EPV = 16 / (int)sizeof(T);
   constexpr int BM = 256, BKB = 128;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GemmParams p, c
   const int NC = p.Cin / BK;
 
   if constexpr (PP) {
-    const int half = wave >> 2;                       // 0: leading half, 1: trails by one slot
+    const int half = pp_phase_half(wave, lane, (unsigned*)(Ws + 2 * WST), pp_mode);   // scratch = head of weight stage 2 (first DMA'd two barriers later);   // 0: leads, 1: trails by one slot
     // prologue: halo of chunk 0, weight items 0 and 1; item 0 (and the halo) must have landed before the first read
 #pragma unroll
     for (int t = 0; t < HALO_NA; ++t) issue_a(t, 0, 0);
@@ -347,7 +348,8 @@ static int launch_halo_cfg(const GemmParams& p, const unsigned char* zero_page, 
   const int tiles = (p.M / 256) * (p.N / BN);
   static const bool no_stage = getenv("TANGO_NO_STAGED_EPILOGUE") != nullptr;   // experiment switch
   const int staged = (!no_stage && epilogue_can_stage<T>(p)) ? 1 : 0;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(512), lds, s, p, zero_page, g.SR, g.nseg, abytes, abl, staged);
+  static const int pp_mode = getenv("TANGO_PP_HALF") ? atoi(getenv("TANGO_PP_HALF")) : 1;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(512), lds, s, p, zero_page, g.SR, g.nseg, abytes, abl, staged, pp_mode);
   TANGO_HIP(hipGetLastError());
   return 0;
 }

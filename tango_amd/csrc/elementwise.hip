@@ -329,13 +329,16 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
     const int t = k / I, i = k - t * I;
     v = src[(int64_t)o * so + (int64_t)t * st + (int64_t)i * si];
   }
-  const int orow = perm ? geglu_row(o, O / 2) : o;
+  int orow = o;
+  if (perm == 1) orow = geglu_row(o, O / 2);
+  else if (perm == 2) orow = 32 * (o >> 4) + (o & 15);          // value half of a gated pair
+  else if (perm == 3) orow = 32 * (o >> 4) + (o & 15) + 16;     // gate half
   dst[(row_off + orow) * Kp + k] = from_f<T>(v);
 }
 
 int launch_pack(int dtype, const float* src, void* dst, int O, int Tn, int I, int64_t so, int64_t st, int64_t si, int64_t Kp,
                 int64_t dst_row_off, hipStream_t s) {
-  const int perm = (int)(dst_row_off < 0);
+  const int perm = dst_row_off < 0 ? (int)(-dst_row_off) : 0;
   const int64_t ro = perm ? 0 : dst_row_off;
   const unsigned nb = (unsigned)(((int64_t)O * Kp + 255) / 256);
   switch (dtype) {
@@ -398,6 +401,82 @@ int launch_fill_zero(void* p, size_t bytes, hipStream_t s) {
 // unused placeholder kept for ABI symmetry with common.h (time MLP runs through gemm<float>)
 int launch_linear_f32(const float*, const float*, const float*, float*, int, int, int, int, int, hipStream_t) {
   TANGO_FAIL("linear_f32: not implemented (use launch_gemm with DT_F32)");
+}
+
+// ------------------------------------------------------------------------------------------
+// Text encoder (FLAN-T5) helpers: embedding gather, T5LayerNorm, relative position bias
+// (transformers models/t5/modeling_t5.py: T5LayerNorm, T5Attention.compute_bias; reference call site models.py:129-147)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                           T* __restrict__ out, int64_t ld, int rows, int D, int vocab) {
+  const int r = blockIdx.x;
+  int64_t id = ids[r];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float* src = table + id * D;
+  T* dst = out + (int64_t)r * ld;
+  for (int c = threadIdx.x * 4; c < D; c += 1024) {
+    const f32x4 v = *(const f32x4*)(src + c);
+    dst[c] = from_f<T>(v[0]); dst[c + 1] = from_f<T>(v[1]); dst[c + 2] = from_f<T>(v[2]); dst[c + 3] = from_f<T>(v[3]);
+  }
+}
+int launch_embed_gather(int dtype, const int64_t* ids, const float* table, void* out, int64_t ld, int rows, int D, int vocab, hipStream_t s) {
+  if (D % 4 != 0) TANGO_FAIL("embed_gather: d_model must be a multiple of 4");
+  switch (dtype) {
+    case DT_F32: hipLaunchKernelGGL((embed_gather_kernel<float>), dim3((unsigned)rows), dim3(256), 0, s, ids, table, (float*)out, ld, rows, D, vocab); break;
+    case DT_F16: hipLaunchKernelGGL((embed_gather_kernel<f16>), dim3((unsigned)rows), dim3(256), 0, s, ids, table, (f16*)out, ld, rows, D, vocab); break;
+    case DT_BF16: hipLaunchKernelGGL((embed_gather_kernel<bf16>), dim3((unsigned)rows), dim3(256), 0, s, ids, table, (bf16*)out, ld, rows, D, vocab); break;
+    default: TANGO_FAIL("embed_gather: bad dtype");
+  }
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+// one wave per row; fp32 statistics (T5LayerNorm computes the variance in fp32 as well)
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, int64_t ldx, void* __restrict__ y, int64_t ldy,
+                                                      const float* __restrict__ gamma, int rows, int C, float eps, int out_f32) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * ldx;
+  float q = 0.f;
+  for (int c = lane; c < C; c += 64) { const float f = to_f(xr[c]); q += f * f; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q / (float)C + eps);
+  for (int c = lane; c < C; c += 64) {
+    const float v = to_f(xr[c]) * rstd * gamma[c];
+    if (out_f32) ((float*)y)[(int64_t)row * ldy + c] = v;
+    else ((T*)y)[(int64_t)row * ldy + c] = from_f<T>(v);
+  }
+}
+int launch_rmsnorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, int rows, int C, float eps, int out_f32,
+                   hipStream_t s) {
+  const unsigned nb = (unsigned)((rows + 3) / 4);
+  switch (dtype) {
+    case DT_F32: hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)x, ldx, y, ldy, gamma, rows, C, eps, out_f32); break;
+    case DT_F16: hipLaunchKernelGGL((rmsnorm_kernel<f16>), dim3(nb), dim3(256), 0, s, (const f16*)x, ldx, y, ldy, gamma, rows, C, eps, out_f32); break;
+    case DT_BF16: hipLaunchKernelGGL((rmsnorm_kernel<bf16>), dim3(nb), dim3(256), 0, s, (const bf16*)x, ldx, y, ldy, gamma, rows, C, eps, out_f32); break;
+    default: TANGO_FAIL("rmsnorm: bad dtype");
+  }
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void t5_pos_bias_kernel(const float* __restrict__ table, const int* __restrict__ bucket,
+                                                          float* __restrict__ out, int heads, int L) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)heads * L * L) return;
+  const int h = (int)(idx / ((int64_t)L * L));
+  const int ij = (int)(idx - (int64_t)h * L * L);
+  out[idx] = table[bucket[ij] * heads + h];
+}
+int launch_t5_pos_bias(const float* table, const int* bucket, float* out, int heads, int L, hipStream_t s) {
+  const int64_t n = (int64_t)heads * L * L;
+  hipLaunchKernelGGL(t5_pos_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, table, bucket, out, heads, L);
+  TANGO_HIP(hipGetLastError());
+  return 0;
 }
 
 }  // namespace tango

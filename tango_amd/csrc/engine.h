@@ -117,6 +117,20 @@ struct UNetPlan {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
 };
+struct T5LayerW {          // T5Block of the encoder: self-attention + gated-GELU feed-forward (no biases anywhere)
+  WNorm ln1, ln2;
+  WMat qkv, o, wi, wo;     // qkv = fused [q; k; v] rows; wi = [wi_1 | wi_0] in the GLU interleave (value | gate)
+};
+struct T5Plan {
+  int B = 0, L = 0;
+  char* slab = nullptr;
+  Program prog;
+  int64_t* ids = nullptr;   // [B*L]
+  float* bias = nullptr;    // [B*L] additive key mask
+  int* bucket = nullptr;    // [L*L] relative-position buckets (host-computed)
+  float* pos_bias = nullptr;  // [heads][L][L]
+  float* out = nullptr;     // [B*L][d_model] fp32
+};
 struct VaePlan {           // also used for the vocoder: plan-owned in/out staging buffers
   int B = 0;
   char* slab = nullptr;
@@ -140,6 +154,7 @@ class Engine {
   int vae_decode(const float* lat, float* mel, int B, hipStream_t s);
   int vocode(const float* mel, int16_t* wav, int B, int frames, int* n_samples, hipStream_t s);
   int vocoder_samples(int frames) const;
+  int encode_text(const int64_t* ids, const uint8_t* mask, float* out, int B, int L, hipStream_t s);
   int last_denoise_ms(float* total_ms, float* per_step_ms);
   int profile_unet(int B2, int L, std::string& report, hipStream_t s);
 
@@ -173,6 +188,7 @@ class Engine {
   void build_unet_weights();
   void build_vae_weights();
   void build_voc_weights();
+  void build_t5_weights();
 
   // ---- model weights ----
   // UNet
@@ -199,6 +215,15 @@ class Engine {
   WMat voc_pre, voc_post;
   std::vector<ConvTW> voc_ups;
   std::vector<VocResW> voc_res;
+
+  // text encoder
+  float* t5_embed = nullptr;        // [vocab][d_model] fp32
+  float* t5_rel_table = nullptr;    // [rel_buckets][heads] fp32
+  std::vector<T5LayerW> t5_layers;
+  WNorm t5_final_ln;
+  std::map<std::pair<int, int>, std::unique_ptr<T5Plan>> t5_plans;
+  int get_t5_plan(int B, int L, T5Plan** out);
+  int build_t5(T5Plan& P, Arena& A, bool record);
 
   // ---- runtime state ----
   int* d_step = nullptr;

@@ -36,6 +36,7 @@ struct GOpt {
   int vt_n0 = 0, vt_S = 1;
   int64_t vt_ld = 0;
   const WNorm* ln = nullptr;     // apply LayerNorm(ln) to the input rows first (folded when the streaming kernel applies)
+  int glu_tanh = 0;              // EPI_GEGLU gate: tanh GELU (T5 gated-gelu) instead of exact-erf GELU
 };
 
 struct Builder {
@@ -93,7 +94,7 @@ struct Builder {
     p.mode = GATHER_1D; p.rows_pb = (int)rows; p.Lin = (int)rows; p.Lout = (int)rows; p.taps = 1;
     p.out = out.p; p.ldo = out.ld; p.out_f32 = o.out_f32;
     if (o.residual) { p.R = o.residual->p; p.ldr = o.residual->ld; }
-    p.a_act = o.a_act; p.a_slope = o.a_slope; p.e_act = o.e_act; p.e_slope = o.e_slope; p.epi = o.epi;
+    p.a_act = o.a_act; p.a_slope = o.a_slope; p.e_act = o.e_act; p.e_slope = o.e_slope; p.epi = o.epi; p.glu_tanh = o.glu_tanh;
     p.bias2 = o.bias2; p.bias2_stride = o.bias2_stride; p.step_ptr = o.bias2 ? E.d_step : nullptr;
     if (o.vt) { p.epi = EPI_VT; p.vt = o.vt; p.vt_n0 = o.vt_n0; p.vt_S = o.vt_S; p.vt_ld = o.vt_ld; }
     if (o.ln) {
@@ -165,10 +166,10 @@ struct Builder {
   }
 
   void attention(const TView& q, const TView& k, const void* vt, int64_t ldvt, const TView& o, const float* bias, int B, int heads,
-                 int Sq, int Skv) {
+                 int Sq, int Skv, float scale = 0.125f, const float* pos_bias = nullptr) {
     AttnParams p;
     p.q = q.p; p.ldq = q.ld; p.k = k.p; p.ldk = k.ld; p.vt = vt; p.ldvt = ldvt; p.o = o.p; p.ldo = o.ld;
-    p.bias = bias; p.B = B; p.heads = heads; p.Sq = Sq; p.Skv = Skv; p.scale = 0.125f;
+    p.bias = bias; p.pos_bias = pos_bias; p.B = B; p.heads = heads; p.Sq = Sq; p.Skv = Skv; p.scale = scale;
     const int d = dt;
     push([p, d](hipStream_t s) { return launch_attention(d, p, s); },
          "attention Sq=" + std::to_string(Sq) + " Skv=" + std::to_string(Skv) + " heads=" + std::to_string(heads),
@@ -246,6 +247,7 @@ Engine::~Engine() {
   }
   for (auto& kv : vae_plans) if (kv.second->slab) (void)hipFree(kv.second->slab);
   for (auto& kv : voc_plans) if (kv.second->slab) (void)hipFree(kv.second->slab);
+  for (auto& kv : t5_plans) if (kv.second->slab) (void)hipFree(kv.second->slab);
   for (void* p : owned) (void)hipFree(p);
   if (cap_stream) (void)hipStreamDestroy(cap_stream);
   if (ev0) (void)hipEventDestroy(ev0);
@@ -589,6 +591,11 @@ int Engine::init() {
   }
   if (cfg.vae_levels > 0) build_vae_weights();
   if (cfg.voc_n_ups > 0) build_voc_weights();
+  if (cfg.t5_layers > 0) {
+    if (cfg.t5_d_kv != 64) TANGO_FAIL("engine: T5 d_kv must be 64 (attention head_dim)");
+    if (cfg.t5_d_model % 16 || cfg.t5_d_ff % 16) TANGO_FAIL("engine: T5 d_model / d_ff must be multiples of 16");
+    build_t5_weights();
+  }
   for (void* p : owned) if (!p) return -1;
   TANGO_HIP(hipEventCreate(&ev0));
   TANGO_HIP(hipEventCreate(&ev1));
@@ -947,6 +954,152 @@ int Engine::last_denoise_ms(float* total_ms, float* per_step_ms) {
 }
 
 // ================================================================================================
+// FLAN-T5 encoder (transformers models/t5/modeling_t5.py T5Stack encoder; reference call sites models.py:98-100,129-147):
+// embedding -> 24 x [RMSNorm -> self-attention with shared relative position bias (no 1/sqrt(d) scaling) -> +residual,
+// RMSNorm -> gated-GELU feed-forward -> +residual] -> final RMSNorm.  No biases, no dropout at inference.
+// ================================================================================================
+void Engine::build_t5_weights() {
+  const int d = cfg.t5_d_model, inner = cfg.t5_heads * cfg.t5_d_kv, dff = cfg.t5_d_ff;
+  const std::string P = "text_encoder.";
+  t5_embed = (float*)dmalloc((size_t)cfg.t5_vocab * d * 4);
+  {
+    float* dst = t5_embed;
+    const size_t n = (size_t)cfg.t5_vocab * d * 4;
+    reg_slot(P + "shared.weight", {cfg.t5_vocab, d}, [dst, n](const float* src, hipStream_t s) {
+      TANGO_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s));
+      return 0;
+    });
+  }
+  t5_rel_table = (float*)dmalloc((size_t)cfg.t5_rel_buckets * cfg.t5_heads * 4);
+  {
+    float* dst = t5_rel_table;
+    const size_t n = (size_t)cfg.t5_rel_buckets * cfg.t5_heads * 4;
+    reg_slot(P + "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", {cfg.t5_rel_buckets, cfg.t5_heads},
+             [dst, n](const float* src, hipStream_t s) {
+               TANGO_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s));
+               return 0;
+             });
+  }
+  t5_layers.resize(cfg.t5_layers);
+  for (int i = 0; i < cfg.t5_layers; ++i) {
+    T5LayerW& w = t5_layers[i];
+    const std::string b = P + "encoder.block." + std::to_string(i);
+    w.ln1.C = d; w.ln1.eps = cfg.t5_eps;
+    reg_vec(b + ".layer.0.layer_norm.weight", d, &w.ln1.g);
+    const std::string a = b + ".layer.0.SelfAttention";
+    w.qkv.N = 3 * inner; w.qkv.K = d; w.qkv.Cin = d; w.qkv.Kp = d; w.qkv.taps = 1;
+    w.qkv.W = dmalloc((size_t)3 * inner * d * esz);
+    reg_mat(a + ".q.weight", inner, d, w.qkv, false, 0, {inner, d});
+    reg_mat(a + ".k.weight", inner, d, w.qkv, false, inner, {inner, d});
+    reg_mat(a + ".v.weight", inner, d, w.qkv, false, 2 * inner, {inner, d});
+    reg_linear(a + ".o", d, inner, w.o, false);
+    w.ln2.C = d; w.ln2.eps = cfg.t5_eps;
+    reg_vec(b + ".layer.1.layer_norm.weight", d, &w.ln2.g);
+    // gated feed-forward: hidden = gelu_new(wi_0 x) * (wi_1 x) -> GLU interleave with wi_1 as the value, wi_0 as the gate
+    const std::string f = b + ".layer.1.DenseReluDense";
+    w.wi.N = 2 * dff; w.wi.K = d; w.wi.Cin = d; w.wi.Kp = d; w.wi.taps = 1;
+    w.wi.W = dmalloc((size_t)2 * dff * d * esz);
+    {
+      void* W = w.wi.W;
+      const int dt_ = dt;
+      reg_slot(f + ".wi_1.weight", {dff, d}, [=](const float* src, hipStream_t s) { return launch_pack(dt_, src, W, dff, 1, d, d, 0, 1, d, -2, s); });
+      reg_slot(f + ".wi_0.weight", {dff, d}, [=](const float* src, hipStream_t s) { return launch_pack(dt_, src, W, dff, 1, d, d, 0, 1, d, -3, s); });
+    }
+    reg_linear(f + ".wo", d, dff, w.wo, false);
+  }
+  t5_final_ln.C = d; t5_final_ln.eps = cfg.t5_eps;
+  reg_vec(P + "encoder.final_layer_norm.weight", d, &t5_final_ln.g);
+}
+
+// T5Attention._relative_position_bucket (bidirectional), float32 arithmetic in the reference's operation order
+static int t5_bucket(int rel /* memory - query */, int num_buckets, int max_distance) {
+  int nb = num_buckets / 2;
+  int ret = rel > 0 ? nb : 0;
+  int rp = rel < 0 ? -rel : rel;
+  const int max_exact = nb / 2;
+  if (rp < max_exact) return ret + rp;
+  const float v = logf((float)rp / (float)max_exact) / (float)std::log((double)max_distance / (double)max_exact) * (float)(nb - max_exact);
+  int large = max_exact + (int)v;
+  if (large > nb - 1) large = nb - 1;
+  return ret + large;
+}
+
+int Engine::build_t5(T5Plan& P, Arena& A, bool record) {
+  Builder b{*this, A, &P.prog, record, dt, esz};
+  const int B = P.B, L = P.L, d = cfg.t5_d_model, H = cfg.t5_heads, inner = H * cfg.t5_d_kv, dff = cfg.t5_d_ff;
+  const int64_t rows = (int64_t)B * L;
+  const int Lp = (L + 7) / 8 * 8;
+  P.ids = (int64_t*)A.alloc((size_t)rows * 8);
+  P.bias = (float*)A.alloc((size_t)rows * 4);
+  P.bucket = (int*)A.alloc((size_t)L * L * 4);
+  P.pos_bias = (float*)A.alloc((size_t)H * L * L * 4);
+  P.out = (float*)A.alloc((size_t)rows * d * 4);
+  TView h = b.alloc(rows, d), n = b.alloc(rows, d), h2 = b.alloc(rows, d);
+  TView qk = b.alloc(rows, 2 * inner);
+  void* vt = A.alloc((size_t)B * inner * Lp * esz);     // V^T [B][inner][Lp]; pad columns stay zero (slab is zero-filled)
+  TView att = b.alloc(rows, inner);
+  TView gg = b.alloc(rows, dff);
+  const int d_ = dt;
+  {
+    const int64_t* ids = P.ids; const float* tab = t5_embed; void* hp = h.p; const int V = cfg.t5_vocab; const int r = (int)rows;
+    b.push([=](hipStream_t s) { return launch_embed_gather(d_, ids, tab, hp, d, r, d, V, s); }, "t5 embedding");
+  }
+  auto rms = [&](const TView& x, const WNorm& w, void* y, int64_t ldy, int out_f32) {
+    const void* xp = x.p; const int64_t ldx = x.ld; const float* g = w.g; const float eps = w.eps; const int r = (int)rows;
+    b.push([=](hipStream_t s) { return launch_rmsnorm(d_, xp, ldx, y, ldy, g, r, d, eps, out_f32, s); }, "t5 rmsnorm");
+  };
+  for (int i = 0; i < cfg.t5_layers; ++i) {
+    const T5LayerW& w = t5_layers[i];
+    rms(h, w.ln1, n.p, n.ld, 0);
+    { GOpt o; o.use_bias = false; o.vt = vt; o.vt_n0 = 2 * inner; o.vt_S = L; o.vt_ld = Lp; b.linear(n, rows, w.qkv, qk, o); }
+    b.attention(Builder::slice(qk, 0, inner, esz), Builder::slice(qk, inner, inner, esz), vt, Lp, att, P.bias, B, H, L, L, 1.0f, P.pos_bias);
+    { GOpt o; o.use_bias = false; o.residual = &h; b.linear(att, rows, w.o, h2, o); }
+    rms(h2, w.ln2, n.p, n.ld, 0);
+    { GOpt o; o.use_bias = false; o.epi = EPI_GEGLU; o.glu_tanh = 1; b.linear(n, rows, w.wi, gg, o); }
+    { GOpt o; o.use_bias = false; o.residual = &h2; b.linear(gg, rows, w.wo, h, o); }
+  }
+  rms(h, t5_final_ln, P.out, d, 1);
+  return 0;
+}
+
+int Engine::get_t5_plan(int B, int L, T5Plan** out) {
+  auto key = std::make_pair(B, L);
+  auto it = t5_plans.find(key);
+  if (it != t5_plans.end()) { *out = it->second.get(); return 0; }
+  if (!finalized) TANGO_FAIL("engine: weights not finalized");
+  std::unique_ptr<T5Plan> P(new T5Plan());
+  P->B = B; P->L = L;
+  Arena m;
+  TANGO_TRY(build_t5(*P, m, false));
+  TANGO_HIP(hipMalloc((void**)&P->slab, m.peak + 256));
+  TANGO_HIP(hipMemset(P->slab, 0, m.peak + 256));
+  Arena a; a.base = P->slab;
+  P->prog.ops.clear(); P->prog.labels.clear(); P->prog.flops.clear();
+  TANGO_TRY(build_t5(*P, a, true));
+  std::vector<int> bk((size_t)L * L);
+  for (int i = 0; i < L; ++i)
+    for (int j = 0; j < L; ++j) bk[(size_t)i * L + j] = t5_bucket(j - i, cfg.t5_rel_buckets, cfg.t5_rel_max_distance);
+  TANGO_HIP(hipMemcpy(P->bucket, bk.data(), bk.size() * 4, hipMemcpyHostToDevice));
+  *out = P.get();
+  t5_plans[key] = std::move(P);
+  return 0;
+}
+
+int Engine::encode_text(const int64_t* ids, const uint8_t* mask, float* out, int B, int L, hipStream_t s) {
+  if (cfg.t5_layers <= 0) TANGO_FAIL("engine: text encoder not configured");
+  if (B <= 0 || L <= 0) TANGO_FAIL("encode_text: empty batch");
+  T5Plan* P;
+  TANGO_TRY(get_t5_plan(B, L, &P));
+  TANGO_HIP(hipMemcpyAsync(P->ids, ids, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s));
+  if (mask) TANGO_TRY(launch_mask_bias(mask, P->bias, B * L, s));
+  else TANGO_TRY(launch_fill_zero(P->bias, (size_t)B * L * 4, s));
+  TANGO_TRY(launch_t5_pos_bias(t5_rel_table, P->bucket, P->pos_bias, cfg.t5_heads, L, s));   // table may have been reloaded
+  TANGO_TRY(P->prog.run(s));
+  TANGO_HIP(hipMemcpyAsync(out, P->out, (size_t)B * L * cfg.t5_d_model * 4, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+// ================================================================================================
 // mel-VAE decoder plan (autoencoder.py:116-124,60-64; modules.py:650-683)
 // ================================================================================================
 int Engine::build_vae(VaePlan& P, Arena& A, bool record) {
@@ -1261,6 +1414,10 @@ int tango_engine_vocode(tango_engine_t* h, const float* mel, int16_t* wav, int b
   return h->e->vocode(mel, wav, batch, mel_frames, n_samples, (hipStream_t)stream);
 }
 int tango_engine_vocoder_samples(tango_engine_t* h, int mel_frames) { return h->e->vocoder_samples(mel_frames); }
+int tango_engine_encode_text(tango_engine_t* h, const int64_t* input_ids, const uint8_t* attention_mask, float* out, int batch,
+                             int text_len, void* stream) {
+  return h->e->encode_text(input_ids, attention_mask, out, batch, text_len, (hipStream_t)stream);
+}
 
 int tango_engine_profile_unet(tango_engine_t* h, int batch2, int text_len, char* report, int report_cap, void* stream) {
   std::string r;

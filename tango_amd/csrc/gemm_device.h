@@ -130,7 +130,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float gt = acc[a + 1 < TN ? a + 1 : a][b][r] * p.alpha + cg[r];
-          v[r] = v[r] * gelu_erf_f(gt);
+          v[r] = v[r] * glu_gate_f<T>(gt, p.glu_tanh);
         }
       } else if (p.e_act != ACT_NONE) {
 #pragma unroll
@@ -235,7 +235,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4 
           // packed rows: [16 value | 16 gate] column blocks -> output column n/2 (same arithmetic as the direct path)
           const int ag = a + 1 < TN ? a + 1 : a;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = v[r] * gelu_erf_f(acc[ag][b][r] * p.alpha + cb[ag][r]);
+          for (int r = 0; r < 4; ++r) v[r] = v[r] * glu_gate_f<T>(acc[ag][b][r] * p.alpha + cb[ag][r], p.glu_tanh);
         } else if (p.e_act != ACT_NONE) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.e_act, p.e_slope);
@@ -302,6 +302,20 @@ __device__ __forceinline__ void wait_vmcnt_upto8(const int n) {
   else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
+// Phase assignment for the ping-pong loops: 0 for the first wave of this workgroup on its SIMD, 1 for the second (the two
+// must run in opposite phases; which waves share a SIMD is the dispatcher's choice, so it is read from HW_REG_HW_ID at run
+// time -- bits 5:4 = SIMD id -- and exchanged through 8 words of LDS scratch).  Any assignment is CORRECT (both halves
+// execute the same number of barriers); a wrong one only loses the overlap.  mode 0: static wave >> 2 (experiment switch).
+__device__ __forceinline__ int pp_phase_half(const int wave, const int lane, unsigned* scratch8, const int mode) {
+  if (mode == 0) return wave >> 2;
+  const unsigned simd = (__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) >> 4) & 3u;
+  if (lane == 0) scratch8[wave] = simd;
+  __syncthreads();
+  int rank = 0;
+  for (int w = 0; w < wave; ++w) rank += scratch8[w] == simd ? 1 : 0;
+  return __builtin_amdgcn_readfirstlane(rank & 1);
+}
+
 // raw workgroup barrier (no vmcnt drain: LDS-DMAs stay in flight across it) that the scheduler may not move code across
 __device__ __forceinline__ void pp_barrier() {
   __builtin_amdgcn_sched_barrier(0);

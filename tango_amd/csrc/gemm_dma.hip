@@ -21,7 +21,7 @@ namespace tango {
 // (kc, 0) (every read of chunk kc-1, whose stage it refills, retired at least one barrier earlier); every wave waits for
 // its own chunk-(kc+1) DMAs in the read part of phase (kc, 1), at least one barrier before the first read of that chunk.
 template <typename T, int BN, int MODE, bool PP>
-__global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GemmParams p, const unsigned char* zero_page, const int staged) {
+__global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GemmParams p, const unsigned char* zero_page, const int staged, const int pp_mode) {
   constexpr int EPV = 16 / (int)sizeof(T);
   constexpr int BM = 256, BKB = 128;
   constexpr int BK = BKB / (int)sizeof(T);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GemmParams p, co
   const int wrow = (BM + wn * WNR + (lane & 15)) * BKB;
 
   if constexpr (PP) {
-    const int half = wave >> 2;
+    const int half = pp_phase_half(wave, lane, (unsigned*)(dsm + 2 * STAGE), pp_mode);   // scratch = head of stage 2 (first DMA'd two barriers later)
     issue_chunk(0, 0);
     if (nk > 1) issue_chunk(1, 1);
     wait_vmcnt_upto8(nk > 1 ? my_count : 0);          // chunk 0 landed, chunk 1 may stay in flight
@@ -224,7 +224,8 @@ static int launch_dma_cfg(const GemmParams& p, hipStream_t s) {
   const int MT = (p.M + 255) / 256, NT = (p.N + BN - 1) / BN;
   static const bool no_stage = getenv("TANGO_NO_STAGED_EPILOGUE") != nullptr;   // experiment switch
   const int staged = (!no_stage && MODE != MODE_CONV1D && epilogue_can_stage<T>(p)) ? 1 : 0;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)(MT * NT)), dim3(512), LDS, s, p, (const unsigned char*)g_zero_page, staged);
+  static const int pp_mode = getenv("TANGO_PP_HALF") ? atoi(getenv("TANGO_PP_HALF")) : 1;   // 1: SIMD-based phase assignment
+  hipLaunchKernelGGL(kfn, dim3((unsigned)(MT * NT)), dim3(512), LDS, s, p, (const unsigned char*)g_zero_page, staged, pp_mode);
   TANGO_HIP(hipGetLastError());
   return 0;
 }

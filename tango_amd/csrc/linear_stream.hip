@@ -51,7 +51,8 @@ template <typename T> __device__ __forceinline__ void frag_stats(const u32x4& v,
 // LN (folded LayerNorm) is a template parameter: a wave-uniform runtime test in the micro-step loop is not free
 // (the halo conv gained 7-9 % when its ablation tests were compiled out).
 // DBG != 0: diagnostic builds for the race hunt (tools/diag_stream_race.py, TANGO_STREAM_DBG): extra waits at the top of every
-// 16-row epilogue pass -- 1: vmcnt(0) + lgkmcnt(0) + nops, 2: lgkmcnt(0) + nops, 3: nops only
+// 16-row epilogue pass -- 1: vmcnt(0) + lgkmcnt(0) + nops, 2: lgkmcnt(0) + nops, 3: nops only, 4: vmcnt(0) before the second pass
+// only, 5: vmcnt(0) before the first pass only
 template <typename T, int KS, int TN, bool LN, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) {
   constexpr int R = (TN > 5) ? 5 : 10;         // ring depth in k-steps (register budget: acc 8*TN + ring 8*R)
@@ -230,6 +231,8 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
       if (DBG == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");
       if (DBG == 2) asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");
       if (DBG == 3) asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
+      if (DBG == 4 && tm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // only between the two passes (tm = 0 stores done)
+      if (DBG == 5 && tm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // only before the epilogue (ring prefetch landed)
 #pragma unroll
       for (int a = 0; a < TN; ++a) {
         if (p.epi == EPI_GEGLU && (a & 1)) continue;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float gt = rstd[tm] * (acc[a1][tm][r] - mean[tm] * gw[r]) + gb[r];
-            v[r] = v[r] * gelu_erf_f(gt);
+            v[r] = v[r] * gelu_erf_t<T>(gt);
           }
         }
         if (p.R) {
@@ -327,6 +330,7 @@ bool linear_stream_ok(int dtype, const GemmParams& p) {
       p.out_scale != 1.f)
     return false;
   if (p.epi != EPI_NONE && p.epi != EPI_GEGLU && p.epi != EPI_VT) return false;
+  if (p.glu_tanh) return false;                     // the streaming epilogue implements the exact-erf gate only
   if (p.M < 4096) return false;                     // too few row groups to feed 256 CUs
   int tn;
   if (rowb == 640) tn = 10;
@@ -352,6 +356,8 @@ static int stream_t(const GemmParams& p, hipStream_t s) {
       if (p.ln_fold && dbg == 1) return stream_launch<T, 20, 5, true, 1>(p, s);
       if (p.ln_fold && dbg == 2) return stream_launch<T, 20, 5, true, 2>(p, s);
       if (p.ln_fold && dbg == 3) return stream_launch<T, 20, 5, true, 3>(p, s);
+      if (p.ln_fold && dbg == 4) return stream_launch<T, 20, 5, true, 4>(p, s);
+      if (p.ln_fold && dbg == 5) return stream_launch<T, 20, 5, true, 5>(p, s);
     }
     return p.ln_fold ? stream_launch<T, 20, 5, true>(p, s) : stream_launch<T, 20, 5, false>(p, s);
   }

@@ -53,7 +53,7 @@ class Engine:
     """One engine handle = one (device, model) pair; not re-entrant (include/tango_engine.h)."""
 
     def __init__(self, unet: Optional[dict] = None, vae: Optional[dict] = None, hifigan: Optional[dict] = None,
-                 dtype: str = "fp16", device="cuda:0"):
+                 dtype: str = "fp16", device="cuda:0", t5: Optional[dict] = None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("tango_amd.Engine needs a HIP device (no CPU fallback)")
@@ -62,6 +62,7 @@ class Engine:
         self.unet_cfg = normalize_unet_config(unet) if unet is not None else None
         self.vae_cfg = dict(vae) if vae is not None else None
         self.hifigan_cfg = dict(hifigan) if hifigan is not None else None
+        self.t5_cfg = dict(t5) if t5 is not None else None
         c = _lib.TangoConfig()
         c.dtype = _lib.DTYPES[dtype]
         c.latent_h, c.latent_w = 256, 16
@@ -105,6 +106,13 @@ class Engine:
                 c.voc_res_kernels[j] = k
                 for m, d in enumerate(h["resblock_dilation_sizes"][j]):
                     c.voc_res_dilations[j][m] = d
+        if self.t5_cfg is not None:
+            t = self.t5_cfg
+            c.t5_layers, c.t5_d_model, c.t5_d_kv, c.t5_heads = t["num_layers"], t["d_model"], t["d_kv"], t["num_heads"]
+            c.t5_d_ff, c.t5_vocab = t["d_ff"], t["vocab_size"]
+            c.t5_rel_buckets = t.get("relative_attention_num_buckets", 32)
+            c.t5_rel_max_distance = t.get("relative_attention_max_distance", 128)
+            c.t5_eps = t.get("layer_norm_epsilon", 1e-6)
         self._cfg = c
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -132,6 +140,8 @@ class Engine:
             out.update(W.vae_decoder_param_shapes(self.vae_cfg))
         if self.hifigan_cfg is not None:
             out.update(W.hifigan_param_shapes(self.hifigan_cfg))
+        if self.t5_cfg is not None:
+            out.update(W.t5_encoder_param_shapes(self.t5_cfg))
         return out
 
     def set_weight(self, name: str, tensor: torch.Tensor):
@@ -237,6 +247,17 @@ class Engine:
         tot, per = C.c_float(), C.c_float()
         _lib.check(self.lib.tango_engine_last_denoise_ms(self._h, C.byref(tot), C.byref(per)), "last_denoise_ms")
         return tot.value, per.value
+
+    def encode_text(self, input_ids, attention_mask=None):
+        """FLAN-T5 encoder forward: int64 ids [B, L] (+ 0/1 mask) -> fp32 last_hidden_state [B, L, d_model] on the device."""
+        ids = input_ids.detach().to(device=self.device, dtype=torch.int64).contiguous()
+        B, L = ids.shape
+        m = attention_mask.detach().to(self.device).to(torch.uint8).contiguous() if attention_mask is not None else None
+        out = torch.empty((B, L, self.t5_cfg["d_model"]), device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.tango_engine_encode_text(self._h, C.c_void_p(ids.data_ptr()), C.c_void_p(m.data_ptr()) if m is not None else None,
+                                                         C.c_void_p(out.data_ptr()), B, L, _stream_ptr()), "encode_text")
+        return out
 
     def vae_decode(self, latents):
         z = self._f32(latents)

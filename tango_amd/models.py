@@ -19,6 +19,29 @@ from .scheduler import DDIMScheduler, DDPMScheduler  # noqa: F401  (re-exported 
 _TEXT_BUCKETS = (16, 32, 64, 128, 256, 512)
 
 
+def build_pretrained_models(ckpt, vae_config=None, dtype="fp16", device="cuda:0", autoencoder_cls=None):
+    """models.py:27-52 of the reference: build the mel-VAE (+ vocoder) from an AudioLDM `.ckpt`
+    (`{"state_dict": {"first_stage_model.*": ..., "scale_factor": ...}}`); `ckpt` is a path or an already loaded dict.
+    Returns `(vae, None)`: the second item of the reference is the TacotronSTFT wave->mel front-end, which only the
+    training / evaluation side uses and is not built here.  `vae_config` defaults to the AudioLDM
+    first-stage config (audioldm/utils.py:158-181 == mustango/configs/vae_config.json)."""
+    if autoencoder_cls is None:
+        from .autoencoder import AutoencoderKL as autoencoder_cls
+    checkpoint = torch.load(ckpt, map_location="cpu") if isinstance(ckpt, (str, os.PathLike)) else ckpt
+    sd = checkpoint["state_dict"]
+    scale_factor = float(sd["scale_factor"].item() if hasattr(sd["scale_factor"], "item") else sd["scale_factor"])
+    vae_state_dict = {k[len("first_stage_model."):]: v for k, v in sd.items() if k.startswith("first_stage_model.")}
+    cfg = dict(vae_config) if vae_config is not None else dict(
+        image_key="fbank", subband=1, embed_dim=8, time_shuffle=1,
+        ddconfig=dict(double_z=True, z_channels=8, resolution=256, downsample_time=False, in_channels=1, out_ch=1, ch=128,
+                      ch_mult=[1, 2, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0))
+    cfg["scale_factor"] = scale_factor
+    vae = autoencoder_cls(**cfg, dtype=dtype, device=device)
+    vae.load_state_dict(vae_state_dict)
+    vae.eval()
+    return vae, None
+
+
 class _UNetHandle:
     """What callers read off `model.unet` (models.py:227)."""
 
@@ -66,7 +89,17 @@ class AudioDiffusion:
         # (it is built lazily), so the sub-dict is kept and applied by _ensure_text().
         te = {k[len("text_encoder."):]: v for k, v in sd.items() if k.startswith("text_encoder.")}
         self._text_sd = te or None
-        if self.text_encoder is not None:
+        if isinstance(self.text_encoder, str):
+            # text_encoder="engine": run FLAN-T5 on the HIP engine too (tango_amd/text_encoder.py), built from the checkpoint's
+            # own tensors -- no hub access, no PyTorch compute left in generate()
+            if self.text_encoder != "engine":
+                raise ValueError("text_encoder must be a module, None or the string 'engine'")
+            if not te:
+                raise RuntimeError("text_encoder='engine' needs the checkpoint's text_encoder.* tensors")
+            from .text_encoder import T5EncoderOnEngine
+            self.text_encoder = T5EncoderOnEngine.from_state_dict(sd, "text_encoder.", device=self.device)
+            self._text_sd = None
+        elif self.text_encoder is not None:
             self._apply_text_sd()
         return missing
 
@@ -89,6 +122,8 @@ class AudioDiffusion:
 
     # ---- text --------------------------------------------------------------------------------
     def _ensure_text(self):
+        if isinstance(self.text_encoder, str):
+            raise RuntimeError("text_encoder='engine' is built by load_state_dict(); no checkpoint has been loaded yet")
         if self.text_encoder is None or self.tokenizer is None:
             from transformers import AutoTokenizer, T5EncoderModel   # models.py:98-100
             self.tokenizer = AutoTokenizer.from_pretrained(self.text_encoder_name)

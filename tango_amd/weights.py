@@ -191,6 +191,46 @@ def hifigan_param_shapes(cfg: dict, prefix: str = "vocoder.") -> Shapes:
     return out
 
 
+#: google/flan-t5-large and -xl encoder hyper-parameters (their config.json; d_kv is 64 in both)
+T5_CONFIG_LARGE = dict(vocab_size=32128, d_model=1024, d_kv=64, num_heads=16, d_ff=2816, num_layers=24,
+                       relative_attention_num_buckets=32, relative_attention_max_distance=128, layer_norm_epsilon=1e-6)
+T5_CONFIG_XL = dict(T5_CONFIG_LARGE, d_model=2048, num_heads=32, d_ff=5120)
+
+
+def t5_encoder_param_shapes(cfg: dict, prefix: str = "text_encoder.") -> Shapes:
+    """transformers T5EncoderModel.state_dict() for a gated-gelu (v1.1 / FLAN) config, minus the tied `encoder.embed_tokens.weight`."""
+    d, inner, dff = cfg["d_model"], cfg["num_heads"] * cfg["d_kv"], cfg["d_ff"]
+    out: Shapes = {}
+    out[prefix + "shared.weight"] = (cfg["vocab_size"], d)
+    out[prefix + "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"] = (cfg["relative_attention_num_buckets"], cfg["num_heads"])
+    for i in range(cfg["num_layers"]):
+        b = "%sencoder.block.%d" % (prefix, i)
+        for n in ("q", "k", "v"):
+            out["%s.layer.0.SelfAttention.%s.weight" % (b, n)] = (inner, d)
+        out["%s.layer.0.SelfAttention.o.weight" % b] = (d, inner)
+        out["%s.layer.0.layer_norm.weight" % b] = (d,)
+        out["%s.layer.1.DenseReluDense.wi_0.weight" % b] = (dff, d)
+        out["%s.layer.1.DenseReluDense.wi_1.weight" % b] = (dff, d)
+        out["%s.layer.1.DenseReluDense.wo.weight" % b] = (d, dff)
+        out["%s.layer.1.layer_norm.weight" % b] = (d,)
+    out[prefix + "encoder.final_layer_norm.weight"] = (d,)
+    return out
+
+
+def t5_config_from_state_dict(sd, prefix: str = "text_encoder.") -> dict:
+    """Recover the encoder hyper-parameters from the tensors themselves (a checkpoint carries no config.json for them)."""
+    d = sd[prefix + "shared.weight"].shape[1] if prefix + "shared.weight" in sd else sd[prefix + "encoder.embed_tokens.weight"].shape[1]
+    vocab = (sd.get(prefix + "shared.weight", sd.get(prefix + "encoder.embed_tokens.weight"))).shape[0]
+    rel = sd[prefix + "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"]
+    inner = sd[prefix + "encoder.block.0.layer.0.SelfAttention.q.weight"].shape[0]
+    layers = 1 + max(int(k[len(prefix):].split(".")[2]) for k in sd if k.startswith(prefix + "encoder.block."))
+    if prefix + "encoder.block.0.layer.1.DenseReluDense.wi_0.weight" not in sd:
+        raise ValueError("only gated-gelu T5 (v1.1 / FLAN-T5) encoders are supported")
+    return dict(vocab_size=vocab, d_model=d, d_kv=inner // rel.shape[1], num_heads=rel.shape[1],
+                d_ff=sd[prefix + "encoder.block.0.layer.1.DenseReluDense.wi_0.weight"].shape[0], num_layers=layers,
+                relative_attention_num_buckets=rel.shape[0], relative_attention_max_distance=128, layer_norm_epsilon=1e-6)
+
+
 def _is_norm(name: str) -> bool:
     leaf = name.rsplit(".", 2)[-2] if name.count(".") >= 1 else name
     return leaf.startswith("norm") or leaf in ("conv_norm_out", "norm_out")

@@ -159,3 +159,60 @@ def test_batch_inference_driver_writes_reference_layout(tmp_path):
     with pytest.raises(ValueError):
         BI.write_wav(str(tmp_path / "x.wav"), np.zeros(4, np.float32))
     assert BI.generate_and_save(g, [], out_root=str(tmp_path / "o2"), exp_id="9")["Test Instances"] == 0
+
+
+def test_predictor_serving_surface(tmp_path):
+    """cog Predictor (predict.py:29-67): setup() builds one generator per model directory, predict() writes a 16 kHz wav"""
+    import wave
+
+    import numpy as np
+
+    from tango_amd.predict import Predictor
+
+    calls = []
+
+    class FakeTango:
+        def __init__(self, path, device="cuda:0", dtype="fp16", text_encoder=None, tokenizer=None):
+            self.path = path
+
+        def generate(self, prompt, steps=100, guidance=3):
+            calls.append((self.path, prompt, steps, guidance))
+            return (np.arange(1600) % 100).astype(np.int16)
+
+    (tmp_path / "tango2").mkdir()
+    p = Predictor()
+    with pytest.raises(FileNotFoundError):
+        p.setup(model_cache=str(tmp_path), tango_cls=FakeTango)           # tango2-full missing: no silent download
+    p.setup(model_cache=str(tmp_path), names=["tango2"], tango_cls=FakeTango)
+    out = p.predict("a dog barks", "tango2", 7, 2.5, out=str(tmp_path / "o.wav"))
+    assert calls == [(str(tmp_path / "tango2"), "a dog barks", 7, 2.5)]
+    with wave.open(str(out)) as w:
+        assert w.getframerate() == 16000 and w.getnframes() == 1600 and w.getsampwidth() == 2
+    with pytest.raises(KeyError):
+        p.predict("x", "tango2-full", 1, 1.0)
+
+
+def test_build_pretrained_models_from_audioldm_ckpt():
+    """models.py:27-52: `first_stage_model.*` keys and `scale_factor` of an AudioLDM checkpoint feed the VAE"""
+    import torch
+
+    from tango_amd.models import build_pretrained_models
+
+    seen = {}
+
+    class FakeVAE:
+        def __init__(self, **kw):
+            seen["kw"] = kw
+
+        def load_state_dict(self, sd):
+            seen["sd"] = sd
+
+        def eval(self):
+            return self
+
+    ck = {"state_dict": {"scale_factor": torch.tensor(0.9227914214134216), "first_stage_model.decoder.conv_in.weight": torch.zeros(2),
+                         "first_stage_model.vocoder.conv_pre.bias": torch.ones(3), "model.diffusion_model.x": torch.zeros(1)}}
+    vae, stft = build_pretrained_models(ck, autoencoder_cls=FakeVAE)
+    assert stft is None and isinstance(vae, FakeVAE)
+    assert abs(seen["kw"]["scale_factor"] - 0.9227914214134216) < 1e-7 and seen["kw"]["ddconfig"]["ch_mult"] == [1, 2, 4]
+    assert sorted(seen["sd"]) == ["decoder.conv_in.weight", "vocoder.conv_pre.bias"]

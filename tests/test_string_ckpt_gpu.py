@@ -51,7 +51,7 @@ class WhitespaceTokenizer:
 def tiny_t5(seed):
     from transformers import T5Config, T5EncoderModel
     torch.manual_seed(seed)
-    cfg = T5Config(vocab_size=128, d_model=O.UNET_CONFIG_TINY["cross_attention_dim"], d_kv=16, d_ff=128, num_layers=2, num_heads=4,
+    cfg = T5Config(vocab_size=128, d_model=O.UNET_CONFIG_TINY["cross_attention_dim"], d_kv=64, d_ff=128, num_layers=2, num_heads=2,
                    feed_forward_proj="gated-gelu", tie_word_embeddings=False)
     return T5EncoderModel(cfg).eval()
 
@@ -161,3 +161,28 @@ def test_snapshot_errors(snapshot, tmp_path):
     torch.save(bad, d / "pytorch_model_main.bin")
     with pytest.raises(RuntimeError, match="text_encoder"):
         Tango(str(d), dtype="fp32", text_encoder=tiny_t5(1).cuda(), tokenizer=WhitespaceTokenizer())
+
+
+def test_tango_text_encoder_on_engine(snapshot):
+    """text_encoder="engine": the checkpoint's FLAN-T5 tensors run on the HIP engine too -- no torch module, no hub access;
+    embeddings equal the checkpoint encoder's (transformers, CPU fp32) and generation works end to end."""
+    path, t5_ckpt, _, _ = snapshot
+    t = Tango(path, device="cuda:0", dtype="fp32", text_encoder="engine", tokenizer=WhitespaceTokenizer())
+    from tango_amd.text_encoder import T5EncoderOnEngine
+    assert isinstance(t.model.text_encoder, T5EncoderOnEngine)
+    prompts = ["a dog barks twice", "rain"]
+    pe, pm = t.model.encode_text_classifier_free(prompts, 2)
+    tok = WhitespaceTokenizer()
+    b = tok(prompts, max_length=512)
+    with torch.no_grad():
+        cond = t5_ckpt(input_ids=b.input_ids, attention_mask=b.attention_mask)[0].repeat_interleave(2, 0)
+        u = tok([""] * 2, max_length=cond.shape[1], padding="max_length")
+        unc = t5_ckpt(input_ids=u.input_ids, attention_mask=u.attention_mask)[0].repeat_interleave(2, 0)
+    want = torch.cat([unc, cond])
+    valid = pm.cpu()
+    err = ((pe.cpu() - want).abs()[valid].max() / want.abs()[valid].max()).item()
+    print("engine T5 inside Tango: embeddings rel err vs the checkpoint encoder %.3e" % err)
+    assert pe.shape == want.shape and err <= 2e-4
+    torch.manual_seed(3)
+    w1 = t.generate("rain", steps=2, guidance=3)
+    assert w1.dtype == np.int16 and w1.shape == (163872,)
