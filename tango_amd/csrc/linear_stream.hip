@@ -50,10 +50,9 @@ template <typename T> __device__ __forceinline__ void frag_stats(const u32x4& v,
 // KS = K*sizeof(T)/64 k-steps per row, TN = 16-column tiles per panel (BN = 16*TN); ring of R = 10 k-steps
 // LN (folded LayerNorm) is a template parameter: a wave-uniform runtime test in the micro-step loop is not free
 // (the halo conv gained 7-9 % when its ablation tests were compiled out).
-// DBG != 0: diagnostic builds for the race hunt (tools/diag_stream_race.py, TANGO_STREAM_DBG): extra waits at the top of every
-// 16-row epilogue pass -- 1: vmcnt(0) + lgkmcnt(0) + nops, 2: lgkmcnt(0) + nops, 3: nops only, 4: vmcnt(0) before the second pass
-// only, 5: vmcnt(0) before the first pass only
-template <typename T, int KS, int TN, bool LN, int DBG = 0>
+// FIX = false rebuilds the kernel WITHOUT the vmcnt(0) between the two 16-row epilogue passes (see the comment there): only
+// instantiated for the configuration that reproduces the round-1 miscompare (TANGO_STREAM_NOFIX=1, tools/diag_stream_race.py).
+template <typename T, int KS, int TN, bool LN, bool FIX = true>
 __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) {
   constexpr int R = (TN > 5) ? 5 : 10;         // ring depth in k-steps (register budget: acc 8*TN + ring 8*R)
   constexpr int TM = 2;
@@ -228,11 +227,14 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
     }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-      if (DBG == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");
-      if (DBG == 2) asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");
-      if (DBG == 3) asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
-      if (DBG == 4 && tm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // only between the two passes (tm = 0 stores done)
-      if (DBG == 5 && tm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // only before the epilogue (ring prefetch landed)
+      // Round-2 finding (tools/diag_stream_race.py): in the KS = 20 / TN = 5 build, 35 of 300 repetitions
+      // of M=5000 N=1920 K=640 (bf16) returned 16 wrong outputs -- always rows 16..31 of a group, column 14 of a panel -- whose
+      // error is EXACTLY rstd * mean * wsum[col]: the first LDS read of this pass (the wsum constants of tile 0) was consumed
+      // with one dword of lanes 48-63 still holding the register's previous content, although the compiler's counted
+      // s_waitcnt lgkmcnt had retired the read.  It only happens while the first pass's global stores (and the ring prefetch
+      // loads) are in flight: vmcnt(0) here -> 0 of 300 (vmcnt(0) before the FIRST pass only: 19 of 300; lgkmcnt(0) + 32
+      // s_nop: 1 of 300; 64 s_nop: 2 of 300).  Not the MFMA source WAR suspected in round 1 (tools/mfma_war_repro.hip: safe).
+      if (FIX && tm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
       for (int a = 0; a < TN; ++a) {
         if (p.epi == EPI_GEGLU && (a & 1)) continue;
@@ -294,12 +296,12 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
   }
 }
 
-template <typename T, int KS, int TN, bool LN, int DBG = 0>
+template <typename T, int KS, int TN, bool LN, bool FIX = true>
 static int stream_launch(const GemmParams& p, hipStream_t s) {
   constexpr int BN = TN * 16;
   constexpr int LDS = BN * KS * 64 + 8 * 16 * (BN * (int)sizeof(T) + 16) + 2 * BN * 4;   // weight panel + per-wave output staging + constants
   static bool attr_set = false;
-  auto kfn = lin_stream_kernel<T, KS, TN, LN, DBG>;
+  auto kfn = lin_stream_kernel<T, KS, TN, LN, FIX>;
   if (!attr_set) {
     TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
@@ -350,14 +352,9 @@ static int stream_t(const GemmParams& p, hipStream_t s) {
   const int rowb = p.K * (int)sizeof(T);
   if (rowb == 640) return p.ln_fold ? stream_launch<T, 10, 10, true>(p, s) : stream_launch<T, 10, 10, false>(p, s);
   if (rowb == 1280) {
-    if constexpr (sizeof(T) == 2 && TypeTag<T>::dt == DT_BF16) {   // diagnostic variants exist for the failing instantiation only
-      const char* e = getenv("TANGO_STREAM_DBG");
-      const int dbg = e ? atoi(e) : 0;
-      if (p.ln_fold && dbg == 1) return stream_launch<T, 20, 5, true, 1>(p, s);
-      if (p.ln_fold && dbg == 2) return stream_launch<T, 20, 5, true, 2>(p, s);
-      if (p.ln_fold && dbg == 3) return stream_launch<T, 20, 5, true, 3>(p, s);
-      if (p.ln_fold && dbg == 4) return stream_launch<T, 20, 5, true, 4>(p, s);
-      if (p.ln_fold && dbg == 5) return stream_launch<T, 20, 5, true, 5>(p, s);
+    if constexpr (sizeof(T) == 2 && TypeTag<T>::dt == DT_BF16) {   // the unfixed build exists for the reproducing configuration only
+      static const bool nofix = getenv("TANGO_STREAM_NOFIX") != nullptr;
+      if (p.ln_fold && nofix) return stream_launch<T, 20, 5, true, false>(p, s);
     }
     return p.ln_fold ? stream_launch<T, 20, 5, true>(p, s) : stream_launch<T, 20, 5, false>(p, s);
   }

@@ -6,7 +6,8 @@ the 80-column panel) and WHAT the wrong values look like next to candidate expla
   * `nolast`  : the same output with the last 64-byte k-step of x dropped (a missed final MFMA)
   * `prevgrp` : the value 256 rows earlier in the same column (the wave's previous 32-row group: a stale accumulator)
   * `bias`    : the epilogue constants only (accumulator read as zero)
-usage (GPU box): REPS=300 DTYPE=bf16 python tools/diag_stream_race.py        # add TANGO_NO_STAGED_EPILOGUE=1 to test direct stores
+usage (GPU box): REPS=300 DTYPE=bf16 python tools/diag_stream_race.py   # TANGO_STREAM_NOFIX=1: the build without the vmcnt(0) fix
+                 # (reproduces 35 / 300); TANGO_NO_STAGED_EPILOGUE=1: direct stores
 """
 import ctypes as C
 import os
@@ -53,6 +54,7 @@ kel = 64 // (2 if dtype != "fp32" else 4)           # elements in the last 64-by
 acc_nolast = x[:, :K - kel] @ wf[:, :K - kel].t()
 nolast = rstd * (acc_nolast - mu * wsum) + bfold
 biasonly = rstd * (0 - mu * wsum) + bfold
+nowsum = rstd * (x @ wf.t()) + bfold                 # the wsum constant read as 0 (what round 2 found)
 nbad = 0
 for rep in range(reps):
     out = run()
@@ -67,9 +69,9 @@ for rep in range(reps):
              c0 % 80, c0 // 80))
     for (r, c) in bad[:4].tolist():
         prev = good[r - 256, c].item() if r >= 256 else float("nan")
-        print("   [%d,%d] bad % .5f good % .5f ref % .5f | nolast % .5f prevgrp % .5f bias-only % .5f | bad-good % .5f"
+        print("   [%d,%d] bad % .5f good % .5f ref % .5f | nolast % .5f prevgrp % .5f bias-only % .5f wsum-read-as-0 % .5f | bad-good % .5f"
               % (r, c, out[r, c].item(), good[r, c].item(), ref[r, c].item(), nolast[r, c].item(), prev, biasonly[r, c].item(),
-                 (out[r, c] - good[r, c]).item()))
+                 nowsum[r, c].item(), (out[r, c] - good[r, c]).item()))
     # does the deficit equal ONE k-step's contribution (a single MFMA of the chain lost / fed a stale operand)?
     (r, c) = bad[0].tolist()
     d = (out[r, c] - good[r, c]).item()
