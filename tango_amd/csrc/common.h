@@ -59,25 +59,10 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
 }
-// Branch-free erf for 16-bit outputs: Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 (fp16 / bf16 epsilon is 1e-3 / 8e-3).
-// libm's erff is two branchy ~25-op paths that a wave executes BOTH of; in the K = 320 GEGLU epilogue that VALU time equals
-// the MFMA time of the whole tile (1280 flops per gated output).  ~12 VALU + v_rcp + v_exp here.
-__device__ __forceinline__ float erf_as_f(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
-  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-  p = __builtin_fmaf(p, t, 1.421413741f);
-  p = __builtin_fmaf(p, t, -0.284496736f);
-  p = __builtin_fmaf(p, t, 0.254829592f);
-  p *= t;
-  const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
-  const float r = __builtin_fmaf(-p, e, 1.0f);
-  return __builtin_copysignf(r, x);
-}
-template <typename T> __device__ __forceinline__ float gelu_erf_t(float x) {
-  if constexpr (sizeof(T) == 4) return gelu_erf_f(x);          // fp32 engine: libm erff (parity path)
-  else return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f));
-}
+// (round 2, measured: a branch-free Abramowitz-Stegun erf -- 12 VALU + v_rcp + v_exp -- in the 16-bit GEGLU epilogues is
+//  SLOWER than libm's erff: 4.02 vs 3.33 ms on the level-1 GEGLU GEMMs; the two transcendentals cost more than the
+//  polynomial path erff takes for |x| < 1, which is where almost all gate inputs are.  erff stays.)
+template <typename T> __device__ __forceinline__ float gelu_erf_t(float x) { return gelu_erf_f(x); }
 // gate activation of the fused gated-linear-unit epilogue: exact-erf GELU (diffusers GEGLU) or tanh GELU (T5 gated-gelu)
 template <typename T> __device__ __forceinline__ float glu_gate_f(float x, int tanh_form) {
   return tanh_form ? gelu_tanh_f(x) : gelu_erf_t<T>(x);
@@ -165,6 +150,8 @@ struct GemmParams {
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s);
 bool conv_halo_ok(int dtype, const GemmParams& p);
 int launch_conv_halo(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s);
+bool gemm_pers_ok(int dtype, const GemmParams& p);   // persistent LDS-DMA GEMM for the big linears (gemm_pers.hip)
+int launch_gemm_pers(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s);
 bool gemm_dma_ok(int dtype, const GemmParams& p);
 int launch_gemm_dma(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s);
 int gemm_init();   // process-wide one-time setup (zero page); call before any launch and outside stream capture

@@ -325,6 +325,7 @@ int launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
   if (linear_stream_ok(dtype, p)) return launch_linear_stream(dtype, p, s);
   if (p.ln_fold) TANGO_FAIL("gemm: ln_fold is only implemented by the streaming linear kernel");
   if (conv_halo_ok(dtype, p)) return launch_conv_halo(dtype, p, g_zero_page, s);
+  if (gemm_pers_ok(dtype, p)) return launch_gemm_pers(dtype, p, g_zero_page, s);
   if (gemm_dma_ok(dtype, p)) return launch_gemm_dma(dtype, p, g_zero_page, s);
   switch (dtype) {
     case DT_F32: return launch_t<float>(p, s);

@@ -50,8 +50,8 @@ template <typename T> __device__ __forceinline__ void frag_stats(const u32x4& v,
 // KS = K*sizeof(T)/64 k-steps per row, TN = 16-column tiles per panel (BN = 16*TN); ring of R = 10 k-steps
 // LN (folded LayerNorm) is a template parameter: a wave-uniform runtime test in the micro-step loop is not free
 // (the halo conv gained 7-9 % when its ablation tests were compiled out).
-// FIX = false rebuilds the kernel WITHOUT the vmcnt(0) between the two 16-row epilogue passes (see the comment there): only
-// instantiated for the configuration that reproduces the round-1 miscompare (TANGO_STREAM_NOFIX=1, tools/diag_stream_race.py).
+// FIX = false rebuilds the kernel with the old 16-row staging passes (see SROWS below): only instantiated for the
+// configuration that reproduces the round-1 miscompare (TANGO_STREAM_NOFIX=1, tools/diag_stream_race.py).
 template <typename T, int KS, int TN, bool LN, bool FIX = true>
 __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) {
   constexpr int R = (TN > 5) ? 5 : 10;         // ring depth in k-steps (register budget: acc 8*TN + ring 8*R)
@@ -59,6 +59,12 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
   constexpr int ROWB = KS * 64;                // bytes per weight row
   constexpr int BN = TN * 16;
   static_assert(KS % R == 0, "ring");
+  // Rows staged per output-store pass.  A 16-row pass of an 80-column panel is 160 16-byte pieces = 2.5 wave passes: the
+  // store loop's last iteration then runs with half the wave masked off, and EVERY miscompare of the round-1/2 race hunt
+  // (tools/diag_stream_race.py) sat in the pass right behind such an iteration: the first LDS read after it returned 0 in
+  // one dword of lanes 48-63.  Staging both 16-row halves (32 rows = 320 pieces = 5 full iterations) removes the partially
+  // masked store iteration altogether; the 160-column panels (320 pieces per 16 rows) never had one.
+  constexpr int SROWS = (FIX && (16 * (BN * (int)sizeof(T) / 16)) % 64 != 0) ? 32 : 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];   // [BN][ROWB], swizzled per 128-byte segment
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
     }
   }
   {   // per-column epilogue constants of this panel: [bias | wsum] (fp32), read back through lgkmcnt, not vmcnt
-    float* cstw = (float*)(wlds + BN * ROWB + 8 * 16 * (BN * (int)sizeof(T) + 16));
+    float* cstw = (float*)(wlds + BN * ROWB + 8 * SROWS * (BN * (int)sizeof(T) + 16));
     for (int i = tid; i < BN; i += 512) {
       cstw[i] = p.bias ? p.bias[n0 + i] : 0.f;
       cstw[BN + i] = LN ? p.wsum[n0 + i] : 0.f;
@@ -214,8 +220,8 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
     const bool panel_vt = (p.epi == EPI_VT) && n0e >= p.vt_n0;
     const bool stage = p.stage_epi && !panel_vt && !(p.epi == EPI_VT && n0e + BN > p.vt_n0);
     constexpr int SPITCH = BN * (int)sizeof(T) + 16;
-    unsigned char* const stg = wlds + BN * ROWB + wave * (16 * SPITCH);
-    const float* const cst = (const float*)(wlds + BN * ROWB + 8 * 16 * SPITCH);   // [bias BN | wsum BN]
+    unsigned char* const stg = wlds + BN * ROWB + wave * (SROWS * SPITCH);
+    const float* const cst = (const float*)(wlds + BN * ROWB + 8 * SROWS * SPITCH);   // [bias BN | wsum BN]
 
     T rv[TM][TN][4];
     if (p.R) {
@@ -227,14 +233,6 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
     }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-      // Round-2 finding (tools/diag_stream_race.py): in the KS = 20 / TN = 5 build, 35 of 300 repetitions
-      // of M=5000 N=1920 K=640 (bf16) returned 16 wrong outputs -- always rows 16..31 of a group, column 14 of a panel -- whose
-      // error is EXACTLY rstd * mean * wsum[col]: the first LDS read of this pass (the wsum constants of tile 0) was consumed
-      // with one dword of lanes 48-63 still holding the register's previous content, although the compiler's counted
-      // s_waitcnt lgkmcnt had retired the read.  It only happens while the first pass's global stores (and the ring prefetch
-      // loads) are in flight: vmcnt(0) here -> 0 of 300 (vmcnt(0) before the FIRST pass only: 19 of 300; lgkmcnt(0) + 32
-      // s_nop: 1 of 300; 64 s_nop: 2 of 300).  Not the MFMA source WAR suspected in round 1 (tools/mfma_war_repro.hip: safe).
-      if (FIX && tm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
       for (int a = 0; a < TN; ++a) {
         if (p.epi == EPI_GEGLU && (a & 1)) continue;
@@ -266,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) tv[r] = from_f<T>(v[r]);
         if (stage) {
-          __builtin_memcpy(stg + l15 * SPITCH + ocl * (int)sizeof(T), tv, 4 * sizeof(T));
+          __builtin_memcpy(stg + ((SROWS == 32 ? tm * 16 : 0) + l15) * SPITCH + ocl * (int)sizeof(T), tv, 4 * sizeof(T));
         } else if (to_vt) {
           if (rok[tm]) {
             T* vp = (T*)p.vt + vtrow[tm] + (int64_t)(n - p.vt_n0) * p.vt_ld;
@@ -277,14 +275,14 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
           if (rok[tm]) __builtin_memcpy((T*)p.out + orow[tm] * p.ldo + oc, tv, 4 * sizeof(T));
         }
       }
-      if (stage) {
+      if (stage && (SROWS == 16 || tm == TM - 1)) {
         __builtin_amdgcn_wave_barrier();
         constexpr int EPV = 16 / (int)sizeof(T);
         const int ppr = (p.epi == EPI_GEGLU ? BN / 2 : BN) / EPV;           // 16-byte pieces per output row
         const int ocol0 = p.epi == EPI_GEGLU ? (n0e >> 1) : n0e;
-        for (int idx = lane; idx < 16 * ppr; idx += 64) {
+        for (int idx = lane; idx < SROWS * ppr; idx += 64) {
           const int row_l = idx / ppr, pcs = idx - row_l * ppr;
-          const int m = grp * 32 + tm * 16 + row_l;
+          const int m = grp * 32 + (SROWS == 32 ? 0 : tm * 16) + row_l;
           if (m < p.M) {
             const u32x4 t = *(const u32x4*)(stg + row_l * SPITCH + pcs * 16);
             *(u32x4*)((T*)p.out + (int64_t)m * p.ldo + ocol0 + pcs * EPV) = t;
@@ -299,7 +297,8 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
 template <typename T, int KS, int TN, bool LN, bool FIX = true>
 static int stream_launch(const GemmParams& p, hipStream_t s) {
   constexpr int BN = TN * 16;
-  constexpr int LDS = BN * KS * 64 + 8 * 16 * (BN * (int)sizeof(T) + 16) + 2 * BN * 4;   // weight panel + per-wave output staging + constants
+  constexpr int SROWS = (FIX && (16 * (BN * (int)sizeof(T) / 16)) % 64 != 0) ? 32 : 16;
+  constexpr int LDS = BN * KS * 64 + 8 * SROWS * (BN * (int)sizeof(T) + 16) + 2 * BN * 4;   // weight panel + per-wave output staging + constants
   static bool attr_set = false;
   auto kfn = lin_stream_kernel<T, KS, TN, LN, FIX>;
   if (!attr_set) {
@@ -340,7 +339,8 @@ bool linear_stream_ok(int dtype, const GemmParams& p) {
   else return false;
   if (p.N % (16 * tn) != 0) return false;
   // weight panel + per-wave output staging + constants must fit the 160-KB LDS (fp32 rows of 640 bytes do not)
-  if ((long)16 * tn * rowb + 8L * 16 * (16 * tn * esz + 16) + 2L * 16 * tn * 4 > 160 * 1024) return false;
+  const int srows = ((16 * (16 * tn * esz / 16)) % 64 != 0) ? 32 : 16;
+  if ((long)16 * tn * rowb + 8L * srows * (16 * tn * esz + 16) + 2L * 16 * tn * 4 > 160 * 1024) return false;
   if (p.epi == EPI_GEGLU && (tn & 1)) return false;
   if (p.epi == EPI_VT && (p.vt_n0 % 16) != 0) return false;
   if ((p.ldo % 4) || (p.R && (p.ldr % 4))) return false;

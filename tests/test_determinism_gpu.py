@@ -70,7 +70,8 @@ def test_stream_linear_ln_repeat(lib, dtype, M, N, K, geglu, res):
 
 @pytest.mark.parametrize("dtype", ["fp16", "fp32"])
 @pytest.mark.parametrize("M,N,K,res", [(4130, 320, 320, 1), (8200, 640, 640, 0),       # streaming kernel, plain
-                                       (131072, 320, 1280, 1), (65536, 1280, 256, 0),   # wide LDS-DMA GEMM (>= 448 tiles)
+                                       (131072, 320, 1280, 1), (65536, 1280, 256, 0),   # persistent LDS-DMA GEMM (>= 512 tiles, M % 256 == 0)
+                                       (115000, 320, 1280, 1),                          # one-shot wide LDS-DMA GEMM (ragged M)
                                        (300, 640, 1280, 1), (512, 1280, 5120, 0)])      # 4-wave tile kernel, split-K
 def test_linear_repeat(lib, dtype, M, N, K, res):
     if dtype == "fp32" and M > 100000:
@@ -84,6 +85,22 @@ def test_linear_repeat(lib, dtype, M, N, K, res):
     ref = (ref + r if res else ref).cpu()
     repeat(lib, lambda out: lib.tango_op_linear(DT[dtype], p(x), p(w), p(b), p(r), p(out), M, N, K, 0, 0, 0, None),
            (M, N), ref, TOL[dtype], "linear %s M=%d N=%d K=%d" % (dtype, M, N, K))
+
+
+@pytest.mark.parametrize("dtype,M,C,K", [("fp16", 32768, 640, 640), ("bf16", 32768, 640, 640), ("fp16", 16384, 1280, 1280), ("fp32", 32768, 320, 512)])
+def test_persistent_gemm_geglu_repeat(lib, dtype, M, C, K):
+    """persistent LDS-DMA GEMM (gemm_pers.hip) with the fused GEGLU epilogue: x [M, K] @ W [8C, K] -> value * gelu(gate) [M, 4C]
+    (>= 512 tiles of 256 x 128; the plain / residual epilogue of that kernel is covered by test_linear_repeat's large cases)"""
+    g = torch.Generator().manual_seed(M + C + K)
+    x = q(torch.randn(M, K, generator=g), dtype).cuda()
+    w = q(torch.randn(8 * C, K, generator=g) / K ** 0.5, dtype).cuda()
+    b = torch.randn(8 * C, generator=g).cuda()
+    h = F.linear(x, w, b)
+    v, gt = h.chunk(2, dim=-1)
+    ref = (v * F.gelu(gt)).cpu()
+    del h, v, gt
+    repeat(lib, lambda out: lib.tango_op_linear(DT[dtype], p(x), p(w), p(b), None, p(out), M, 8 * C, K, 0, 0, 1, None),
+           (M, 4 * C), ref, TOL[dtype], "persistent GEGLU %s M=%d N=%d K=%d" % (dtype, M, 8 * C, K))
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16", "fp32"])
