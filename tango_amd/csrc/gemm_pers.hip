@@ -171,9 +171,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(const GemmParams p, c
 }
 
 // which problems: plain / GEGLU epilogue into T, M a multiple of 256, whole N tiles, at least two 128-byte k-chunks, and
-// enough tiles that every CU gets several (otherwise the one-shot kernel's dispatch is already balanced)
+// enough tiles that every CU gets several (otherwise the one-shot kernel's dispatch is already balanced).
+// Opt-in (TANGO_PERS_GEMM=1): measured on MI355X it is ~10 % slower than the one-shot kernel on every UNet linear shape
+// (profiles/r2_unet_ops_pers_vs_oneshot.txt) - the hardware dispatcher already overlaps one workgroup's epilogue with the
+// next co-resident workgroup's prologue, and the persistent loop adds VGPR pressure.  Kept for the repeat-run tests.
 bool gemm_pers_ok(int dtype, const GemmParams& p) {
-  static const bool on = getenv("TANGO_NO_PERS_GEMM") == nullptr;
+  static const bool on = getenv("TANGO_PERS_GEMM") != nullptr;
   if (!on) return false;
   const int esz = dtype == DT_F32 ? 4 : 2;
   const bool linear = p.mode == GATHER_1D && p.taps == 1 && p.rows_pb == p.M && p.in_mul == 1 && p.in_off == 0 && p.out_mul == 1 &&

@@ -39,19 +39,29 @@ template <> struct SMma<bf16> {
   }
 };
 
-template <typename T> __device__ __forceinline__ void frag_stats(const u32x4& v, float& s, float& q) {
+// LayerNorm statistics of a row are accumulated as sums of (x - shift) and (x - shift)^2 with shift = the row's first
+// element: the one-pass variance E[d^2] - E[d]^2 then cancels only to the extent the row's mean differs from one of its
+// own elements (a few std), not to the extent |mean| >> std (fp32 rows with mean / std = 100 lost 3 digits without it).
+template <typename T> __device__ __forceinline__ void frag_stats(const u32x4& v, float shift, float& s, float& q) {
   constexpr int EPV = 16 / (int)sizeof(T);
   T e[EPV];
   __builtin_memcpy(e, &v, 16);
 #pragma unroll
-  for (int i = 0; i < EPV; ++i) { const float f = to_f(e[i]); s += f; q += f * f; }
+  for (int i = 0; i < EPV; ++i) { const float f = to_f(e[i]) - shift; s += f; q += f * f; }
+}
+template <typename T> __device__ __forceinline__ float frag_first(const u32x4& v) {
+  T e0;
+  __builtin_memcpy(&e0, &v, sizeof(T));
+  return to_f(e0);
 }
 
 // KS = K*sizeof(T)/64 k-steps per row, TN = 16-column tiles per panel (BN = 16*TN); ring of R = 10 k-steps
 // LN (folded LayerNorm) is a template parameter: a wave-uniform runtime test in the micro-step loop is not free
 // (the halo conv gained 7-9 % when its ablation tests were compiled out).
-// FIX = false rebuilds the kernel with the old 16-row staging passes (see SROWS below): only instantiated for the
-// configuration that reproduces the round-1 miscompare (TANGO_STREAM_NOFIX=1, tools/diag_stream_race.py).
+// FIX = false rebuilds the epilogue's "acc - mean * wsum" as plain C++ (hipcc SLP-vectorises it into v_pk_fma_f32 with
+// op_sel operands behind a v_xor): that form reproduces the round-1 miscompare at K = 640 16-bit (39 of 300 repeats, same
+// box, same call as 0 of 1000 for the FIX form - profiles/r2_race_hunt.txt).  Only instantiated for that one configuration
+// (TANGO_STREAM_NOFIX=1, tools/diag_stream_race.py) so the failing form stays reproducible.
 template <typename T, int KS, int TN, bool LN, bool FIX = true>
 __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) {
   constexpr int R = (TN > 5) ? 5 : 10;         // ring depth in k-steps (register budget: acc 8*TN + ring 8*R)
@@ -59,12 +69,9 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
   constexpr int ROWB = KS * 64;                // bytes per weight row
   constexpr int BN = TN * 16;
   static_assert(KS % R == 0, "ring");
-  // Rows staged per output-store pass.  A 16-row pass of an 80-column panel is 160 16-byte pieces = 2.5 wave passes: the
-  // store loop's last iteration then runs with half the wave masked off, and EVERY miscompare of the round-1/2 race hunt
-  // (tools/diag_stream_race.py) sat in the pass right behind such an iteration: the first LDS read after it returned 0 in
-  // one dword of lanes 48-63.  Staging both 16-row halves (32 rows = 320 pieces = 5 full iterations) removes the partially
-  // masked store iteration altogether; the 160-column panels (320 pieces per 16 rows) never had one.
-  constexpr int SROWS = (FIX && (16 * (BN * (int)sizeof(T) / 16)) % 64 != 0) ? 32 : 16;
+  // Rows staged per output-store pass (round 2: 32-row staging of the 80-column panels, which removes the half-masked
+  // last store iteration, was tried against the race and changed nothing: 154 of 1000)
+  constexpr int SROWS = 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];   // [BN][ROWB], swizzled per 128-byte segment
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -146,7 +153,12 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
     for (int a = 0; a < TN; ++a)
 #pragma unroll
       for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float ssum[TM] = {0.f, 0.f}, ssq[TM] = {0.f, 0.f};
+    float ssum[TM] = {0.f, 0.f}, ssq[TM] = {0.f, 0.f}, shift[TM] = {0.f, 0.f};
+    if (LN) {
+      // ring slot 0 holds k-step 0 of this group's rows; lane l15 (g == 0) holds the row's first element
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) shift[tm] = __shfl(frag_first<T>(xf[0][tm]), l15);
+    }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int ks = u / NH, hh = u % NH;
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
 #pragma unroll
       for (int a = 0; a < H; ++a) wf[nb_][a] = *(const u32x4*)(wbase + (hn * H + a) * 16 * ROWB + koff_of(ksn));
       __builtin_amdgcn_sched_barrier(0);
-      if (LN && hh == 0) { frag_stats<T>(xf[slot][0], ssum[0], ssq[0]); frag_stats<T>(xf[slot][1], ssum[1], ssq[1]); }
+      if (LN && hh == 0) { frag_stats<T>(xf[slot][0], shift[0], ssum[0], ssq[0]); frag_stats<T>(xf[slot][1], shift[1], ssum[1], ssq[1]); }
 #pragma unroll
       for (int a = 0; a < H; ++a) {
         SMma<T>::run(acc[hh * H + a][0], wf[cb_][a], xf[slot][0]);
@@ -189,10 +201,10 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
         float s = ssum[tm], q = ssq[tm];
         s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
         q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
-        const float mu = s / (float)p.K;
-        float var = q / (float)p.K - mu * mu;
+        const float dmu = s / (float)p.K;
+        float var = q / (float)p.K - dmu * dmu;
         var = var < 0.f ? 0.f : var;
-        mean[tm] = mu; rstd[tm] = rsqrtf(var + p.ln_eps);
+        mean[tm] = shift[tm] + dmu; rstd[tm] = rsqrtf(var + p.ln_eps);
       }
     }
     // The epilogue must not contain dependent global-load chains: vmcnt is in-order, so every load -> use here also
@@ -245,14 +257,31 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
         const bool to_vt = (p.epi == EPI_VT) && n >= p.vt_n0;
         float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = rstd[tm] * (acc[a][tm][r] - mean[tm] * cw[r]) + cb[r];
+        for (int r = 0; r < 4; ++r) {
+          if (FIX) {
+            // single-instruction form of acc - mean * wsum, opaque to the SLP vectoriser (see the race notes in DESIGN.md
+            // section 5: every miscompare sat in the v_xor + v_pk_fma_f32 op_sel sequence hipcc builds for elements 2, 3)
+            float t;
+            asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(t) : "v"(mean[tm]), "v"(cw[r]), "v"(acc[a][tm][r]));
+            v[r] = rstd[tm] * t + cb[r];
+          } else {
+            v[r] = rstd[tm] * (acc[a][tm][r] - mean[tm] * cw[r]) + cb[r];
+          }
+        }
         if (p.epi == EPI_GEGLU) {
           const int a1 = a + 1 < TN ? a + 1 : a;
           const f32x4 gb = *(const f32x4*)(cst + a1 * 16 + g4e);
           const f32x4 gw = *(const f32x4*)(cst + BN + a1 * 16 + g4e);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float gt = rstd[tm] * (acc[a1][tm][r] - mean[tm] * gw[r]) + gb[r];
+            float gt;
+            if (FIX) {
+              float t;
+              asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(t) : "v"(mean[tm]), "v"(gw[r]), "v"(acc[a1][tm][r]));
+              gt = rstd[tm] * t + gb[r];
+            } else {
+              gt = rstd[tm] * (acc[a1][tm][r] - mean[tm] * gw[r]) + gb[r];
+            }
             v[r] = v[r] * gelu_erf_t<T>(gt);
           }
         }
@@ -297,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
 template <typename T, int KS, int TN, bool LN, bool FIX = true>
 static int stream_launch(const GemmParams& p, hipStream_t s) {
   constexpr int BN = TN * 16;
-  constexpr int SROWS = (FIX && (16 * (BN * (int)sizeof(T) / 16)) % 64 != 0) ? 32 : 16;
+  constexpr int SROWS = 16;
   constexpr int LDS = BN * KS * 64 + 8 * SROWS * (BN * (int)sizeof(T) + 16) + 2 * BN * 4;   // weight panel + per-wave output staging + constants
   static bool attr_set = false;
   auto kfn = lin_stream_kernel<T, KS, TN, LN, FIX>;
@@ -339,7 +368,7 @@ bool linear_stream_ok(int dtype, const GemmParams& p) {
   else return false;
   if (p.N % (16 * tn) != 0) return false;
   // weight panel + per-wave output staging + constants must fit the 160-KB LDS (fp32 rows of 640 bytes do not)
-  const int srows = ((16 * (16 * tn * esz / 16)) % 64 != 0) ? 32 : 16;
+  const int srows = 16;
   if ((long)16 * tn * rowb + 8L * srows * (16 * tn * esz + 16) + 2L * 16 * tn * 4 > 160 * 1024) return false;
   if (p.epi == EPI_GEGLU && (tn & 1)) return false;
   if (p.epi == EPI_VT && (p.vt_n0 % 16) != 0) return false;

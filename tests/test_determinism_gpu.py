@@ -70,7 +70,7 @@ def test_stream_linear_ln_repeat(lib, dtype, M, N, K, geglu, res):
 
 @pytest.mark.parametrize("dtype", ["fp16", "fp32"])
 @pytest.mark.parametrize("M,N,K,res", [(4130, 320, 320, 1), (8200, 640, 640, 0),       # streaming kernel, plain
-                                       (131072, 320, 1280, 1), (65536, 1280, 256, 0),   # persistent LDS-DMA GEMM (>= 512 tiles, M % 256 == 0)
+                                       (131072, 320, 1280, 1), (65536, 1280, 256, 0),   # LDS-DMA GEMM, large grids (persistent variant when TANGO_PERS_GEMM=1)
                                        (115000, 320, 1280, 1),                          # one-shot wide LDS-DMA GEMM (ragged M)
                                        (300, 640, 1280, 1), (512, 1280, 5120, 0)])      # 4-wave tile kernel, split-K
 def test_linear_repeat(lib, dtype, M, N, K, res):
@@ -89,7 +89,7 @@ def test_linear_repeat(lib, dtype, M, N, K, res):
 
 @pytest.mark.parametrize("dtype,M,C,K", [("fp16", 32768, 640, 640), ("bf16", 32768, 640, 640), ("fp16", 16384, 1280, 1280), ("fp32", 32768, 320, 512)])
 def test_persistent_gemm_geglu_repeat(lib, dtype, M, C, K):
-    """persistent LDS-DMA GEMM (gemm_pers.hip) with the fused GEGLU epilogue: x [M, K] @ W [8C, K] -> value * gelu(gate) [M, 4C]
+    """LDS-DMA GEMM (gemm_dma.hip; gemm_pers.hip under TANGO_PERS_GEMM=1) with the fused GEGLU epilogue: x [M, K] @ W [8C, K] -> value * gelu(gate) [M, 4C]
     (>= 512 tiles of 256 x 128; the plain / residual epilogue of that kernel is covered by test_linear_repeat's large cases)"""
     g = torch.Generator().manual_seed(M + C + K)
     x = q(torch.randn(M, K, generator=g), dtype).cuda()
@@ -100,7 +100,7 @@ def test_persistent_gemm_geglu_repeat(lib, dtype, M, C, K):
     ref = (v * F.gelu(gt)).cpu()
     del h, v, gt
     repeat(lib, lambda out: lib.tango_op_linear(DT[dtype], p(x), p(w), p(b), None, p(out), M, 8 * C, K, 0, 0, 1, None),
-           (M, 4 * C), ref, TOL[dtype], "persistent GEGLU %s M=%d N=%d K=%d" % (dtype, M, 8 * C, K))
+           (M, 4 * C), ref, TOL[dtype], "dma GEGLU %s M=%d N=%d K=%d" % (dtype, M, 8 * C, K))
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16", "fp32"])
