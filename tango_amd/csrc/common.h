@@ -59,13 +59,46 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
 }
-// (round 2, measured: a branch-free Abramowitz-Stegun erf -- 12 VALU + v_rcp + v_exp -- in the 16-bit GEGLU epilogues is
-//  SLOWER than libm's erff: 4.02 vs 3.33 ms on the level-1 GEGLU GEMMs; the two transcendentals cost more than the
-//  polynomial path erff takes for |x| < 1, which is where almost all gate inputs are.  erff stays.)
-template <typename T> __device__ __forceinline__ float gelu_erf_t(float x) { return gelu_erf_f(x); }
-// gate activation of the fused gated-linear-unit epilogue: exact-erf GELU (diffusers GEGLU) or tanh GELU (T5 gated-gelu)
-template <typename T> __device__ __forceinline__ float glu_gate_f(float x, int tanh_form) {
-  return tanh_form ? gelu_tanh_f(x) : gelu_erf_t<T>(x);
+// Exact-erf GELU for the 16-bit engines, two values per call: gelu(x) = h + h * e with h = x / 2 and
+// e = erf(x / sqrt 2) ~ xc * Q(xc^2), xc = clamp(x, +-4.25), Q a degree-8 polynomial (weighted minimax fit pinned to e = 1
+// at the clamp, tools/fit_gelu_poly.py): |gelu error| <= 6e-5 absolute over all x, below half an fp16 ulp of any output
+// >= 0.125 and far below bf16's.  Why: ocml's erff is ~38 VALU instructions including a v_exp, and with 64 lanes both of
+// its branches (|z| < 1 polynomial, exp tail) always execute; a GEGLU epilogue evaluates 40 gates per lane per 32 x 160
+// output block, which made the fused GEGLU GEMMs VALU-bound (~6000 VALU cycles against 3200 MFMA cycles per block).
+// Written on float2 so that hipcc emits v_pk_fma_f32 / v_pk_mul_f32: 15 VALU instructions per PAIR, no transcendentals.
+// (The earlier attempt, a branch-free Abramowitz-Stegun form with v_rcp + v_exp per value, measured SLOWER than erff:
+//  4.02 vs 3.33 ms on the level-1 GEGLU GEMMs.)  The fp32 engine keeps erff: its parity bar is 1e-5.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_erf_poly2(const f32x2_t x) {
+  f32x2_t xc;
+  xc.x = __builtin_amdgcn_fmed3f(x.x, -4.25f, 4.25f);
+  xc.y = __builtin_amdgcn_fmed3f(x.y, -4.25f, 4.25f);
+  const f32x2_t t = xc * xc;
+  f32x2_t q = f32x2_t{1.498029197e-11f, 1.498029197e-11f} + t * 1.123676848e-12f;
+  q = __builtin_elementwise_fma(q, t, f32x2_t{-7.180728823e-09f, -7.180728823e-09f});
+  q = __builtin_elementwise_fma(q, t, f32x2_t{3.825664002e-07f, 3.825664002e-07f});
+  q = __builtin_elementwise_fma(q, t, f32x2_t{-1.045047183e-05f, -1.045047183e-05f});
+  q = __builtin_elementwise_fma(q, t, f32x2_t{1.811638670e-04f, 1.811638670e-04f});
+  q = __builtin_elementwise_fma(q, t, f32x2_t{-2.193588131e-03f, -2.193588131e-03f});
+  q = __builtin_elementwise_fma(q, t, f32x2_t{1.957916536e-02f, 1.957916536e-02f});
+  q = __builtin_elementwise_fma(q, t, f32x2_t{-1.326353318e-01f, -1.326353318e-01f});
+  q = __builtin_elementwise_fma(q, t, f32x2_t{7.977887478e-01f, 7.977887478e-01f});
+  const f32x2_t e = q * xc, h = x * 0.5f;
+  return __builtin_elementwise_fma(h, e, h);
+}
+// gate activation of the fused gated-linear-unit epilogues, four gates at a time: exact-erf GELU (diffusers GEGLU) or
+// tanh GELU (T5 gated-gelu); v[r] *= gate(g[r])
+template <typename T, typename V4> __device__ __forceinline__ void glu_gate4(V4& v, const float g[4], int tanh_form) {
+  if (tanh_form) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = v[r] * gelu_tanh_f(g[r]);
+  } else if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = v[r] * gelu_erf_f(g[r]);
+  } else {
+    const f32x2_t a = gelu_erf_poly2(f32x2_t{g[0], g[1]}), b = gelu_erf_poly2(f32x2_t{g[2], g[3]});
+    v[0] = v[0] * a.x; v[1] = v[1] * a.y; v[2] = v[2] * b.x; v[3] = v[3] * b.y;
+  }
 }
 
 // activation codes shared by prologues / epilogues

@@ -127,11 +127,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha + cb[r] + rb;
       if (p.epi == EPI_GEGLU) {
         // packed rows: [16 value | 16 gate] blocks -> out col = nt/2 + g4 + r
+        float gt[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float gt = acc[a + 1 < TN ? a + 1 : a][b][r] * p.alpha + cg[r];
-          v[r] = v[r] * glu_gate_f<T>(gt, p.glu_tanh);
-        }
+        for (int r = 0; r < 4; ++r) gt[r] = acc[a + 1 < TN ? a + 1 : a][b][r] * p.alpha + cg[r];
+        glu_gate4<T>(v, gt, p.glu_tanh);
       } else if (p.e_act != ACT_NONE) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.e_act, p.e_slope);
@@ -234,8 +233,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4 
         if (geglu) {
           // packed rows: [16 value | 16 gate] column blocks -> output column n/2 (same arithmetic as the direct path)
           const int ag = a + 1 < TN ? a + 1 : a;
+          float gt[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = v[r] * glu_gate_f<T>(acc[ag][b][r] * p.alpha + cb[ag][r], p.glu_tanh);
+          for (int r = 0; r < 4; ++r) gt[r] = acc[ag][b][r] * p.alpha + cb[ag][r];
+          glu_gate4<T>(v, gt, p.glu_tanh);
         } else if (p.e_act != ACT_NONE) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.e_act, p.e_slope);
@@ -337,8 +338,10 @@ __device__ __forceinline__ void gemm_epilogue_staged16(const GemmParams& p, f32x
       for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha + cb[a][r];
       if (geglu) {
         const int ag = a + 1 < TN ? a + 1 : a;
+        float gt[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] * glu_gate_f<T>(acc[ag][b][r] * p.alpha + cb[ag][r], p.glu_tanh);
+        for (int r = 0; r < 4; ++r) gt[r] = acc[ag][b][r] * p.alpha + cb[ag][r];
+        glu_gate4<T>(v, gt, p.glu_tanh);
       } else if (p.e_act != ACT_NONE) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.e_act, p.e_slope);

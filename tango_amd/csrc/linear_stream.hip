@@ -39,15 +39,41 @@ template <> struct SMma<bf16> {
   }
 };
 
-// LayerNorm statistics of a row are accumulated as sums of (x - shift) and (x - shift)^2 with shift = the row's first
-// element: the one-pass variance E[d^2] - E[d]^2 then cancels only to the extent the row's mean differs from one of its
-// own elements (a few std), not to the extent |mean| >> std (fp32 rows with mean / std = 100 lost 3 digits without it).
+// LayerNorm statistics of a row.  fp32 rows: sums of (x - shift) and (x - shift)^2 with shift = the row's first element, so
+// that the one-pass variance E[d^2] - E[d]^2 cancels only to the extent the row's mean differs from one of its own
+// elements (a few std), not to the extent |mean| >> std (fp32 rows with mean / std = 100 lost 3 digits without it).
+// 16-bit rows: v_dot2c_f32_{f16,bf16} on the packed pairs (products exact, fp32 accumulate), 8 VALU instructions per
+// 8-element fragment instead of 24; no shift - the storage rounding of x (2^-11 / 2^-8 of |mean|) already exceeds what
+// the cancellation loses in fp32 (tests/test_determinism_gpu.py::test_linear_ln_large_mean_and_outliers).
 template <typename T> __device__ __forceinline__ void frag_stats(const u32x4& v, float shift, float& s, float& q) {
-  constexpr int EPV = 16 / (int)sizeof(T);
-  T e[EPV];
-  __builtin_memcpy(e, &v, 16);
+  if constexpr (sizeof(T) == 4) {
+    float e[4];
+    __builtin_memcpy(e, &v, 16);
 #pragma unroll
-  for (int i = 0; i < EPV; ++i) { const float f = to_f(e[i]) - shift; s += f; q += f * f; }
+    for (int i = 0; i < 4; ++i) { const float f = e[i] - shift; s += f; q += f * f; }
+  } else if constexpr (__is_same(T, f16)) {
+    // (the pairs are taken with shufflevector: indexing the dwords of the u32x4 reference in an unrolled loop made hipcc
+    //  7.2 emit the FIRST dword four times - caught by the LN parity tests)
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const f16x8 h = __builtin_bit_cast(f16x8, v);
+    const h2 one = h2{(_Float16)1.f, (_Float16)1.f};
+    const h2 p0 = __builtin_shufflevector(h, h, 0, 1), p1 = __builtin_shufflevector(h, h, 2, 3);
+    const h2 p2 = __builtin_shufflevector(h, h, 4, 5), p3 = __builtin_shufflevector(h, h, 6, 7);
+    s = __builtin_amdgcn_fdot2(p0, one, s, false); q = __builtin_amdgcn_fdot2(p0, p0, q, false);
+    s = __builtin_amdgcn_fdot2(p1, one, s, false); q = __builtin_amdgcn_fdot2(p1, p1, q, false);
+    s = __builtin_amdgcn_fdot2(p2, one, s, false); q = __builtin_amdgcn_fdot2(p2, p2, q, false);
+    s = __builtin_amdgcn_fdot2(p3, one, s, false); q = __builtin_amdgcn_fdot2(p3, p3, q, false);
+  } else {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const bf16x8 h = __builtin_bit_cast(bf16x8, v);
+    const b2 one = b2{(__bf16)1.f, (__bf16)1.f};
+    const b2 p0 = __builtin_shufflevector(h, h, 0, 1), p1 = __builtin_shufflevector(h, h, 2, 3);
+    const b2 p2 = __builtin_shufflevector(h, h, 4, 5), p3 = __builtin_shufflevector(h, h, 6, 7);
+    s = __builtin_amdgcn_fdot2_f32_bf16(p0, one, s, false); q = __builtin_amdgcn_fdot2_f32_bf16(p0, p0, q, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(p1, one, s, false); q = __builtin_amdgcn_fdot2_f32_bf16(p1, p1, q, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(p2, one, s, false); q = __builtin_amdgcn_fdot2_f32_bf16(p2, p2, q, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(p3, one, s, false); q = __builtin_amdgcn_fdot2_f32_bf16(p3, p3, q, false);
+  }
 }
 template <typename T> __device__ __forceinline__ float frag_first(const u32x4& v) {
   T e0;
@@ -154,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
 #pragma unroll
       for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     float ssum[TM] = {0.f, 0.f}, ssq[TM] = {0.f, 0.f}, shift[TM] = {0.f, 0.f};
-    if (LN) {
+    if (LN && sizeof(T) == 4) {
       // ring slot 0 holds k-step 0 of this group's rows; lane l15 (g == 0) holds the row's first element
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) shift[tm] = __shfl(frag_first<T>(xf[0][tm]), l15);
@@ -272,18 +298,18 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
           const int a1 = a + 1 < TN ? a + 1 : a;
           const f32x4 gb = *(const f32x4*)(cst + a1 * 16 + g4e);
           const f32x4 gw = *(const f32x4*)(cst + BN + a1 * 16 + g4e);
+          float gt[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float gt;
             if (FIX) {
               float t;
               asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(t) : "v"(mean[tm]), "v"(gw[r]), "v"(acc[a1][tm][r]));
-              gt = rstd[tm] * t + gb[r];
+              gt[r] = rstd[tm] * t + gb[r];
             } else {
-              gt = rstd[tm] * (acc[a1][tm][r] - mean[tm] * gw[r]) + gb[r];
+              gt[r] = rstd[tm] * (acc[a1][tm][r] - mean[tm] * gw[r]) + gb[r];
             }
-            v[r] = v[r] * gelu_erf_t<T>(gt);
           }
+          glu_gate4<T>(v, gt, 0);
         }
         if (p.R) {
 #pragma unroll

@@ -1,10 +1,11 @@
 #!/bin/bash
-# gpurun call 7 of round 2: race hunt -- asm-FMA build of the LN epilogue, plain variant, K = 320 variant
+# gpurun call 11 of round 2: packed-fma GELU + dot2 LayerNorm statistics -- correctness, repeat-run stress, per-op table
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r2; mkdir -p $O
-REPS=1000 DTYPE=bf16 timeout 300 python tools/diag_stream_race.py > $O/race_asmfma_bf16.txt 2>&1; echo "asm-fma LN bf16 K=640: $(tail -1 $O/race_asmfma_bf16.txt)"
-TANGO_STREAM_NOFIX=1 REPS=300 DTYPE=bf16 timeout 300 python tools/diag_stream_race.py > $O/race_nofix3_bf16.txt 2>&1; echo "nofix LN bf16 K=640: $(tail -1 $O/race_nofix3_bf16.txt)"
-REPS=1000 DTYPE=fp16 timeout 300 python tools/diag_stream_race.py > $O/race_asmfma_fp16.txt 2>&1; echo "asm-fma LN fp16 K=640: $(tail -1 $O/race_asmfma_fp16.txt)"
-PLAIN=1 REPS=1000 DTYPE=bf16 timeout 300 python tools/diag_stream_race.py > $O/race_plain_bf16.txt 2>&1; echo "plain bf16 K=640: $(tail -1 $O/race_plain_bf16.txt)"
-SHAPE=5000,1920,320 REPS=1000 DTYPE=bf16 timeout 300 python tools/diag_stream_race.py > $O/race_k320_bf16.txt 2>&1; echo "asm-fma LN bf16 K=320: $(tail -1 $O/race_k320_bf16.txt)"
-SHAPE=5000,1920,320 PLAIN=1 REPS=600 DTYPE=fp16 timeout 300 python tools/diag_stream_race.py > $O/race_k320_plain_fp16.txt 2>&1; echo "plain fp16 K=320: $(tail -1 $O/race_k320_plain_fp16.txt)"
+timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -q -x > $O/ops_v24.log 2>&1; echo "ops rc=$?"; tail -2 $O/ops_v24.log
+timeout 900 python -m pytest tests/test_determinism_gpu.py -m gpu -q -k "linear or gemm" > $O/det_v24.log 2>&1; echo "det rc=$?"; tail -2 $O/det_v24.log
+REPS=500 DTYPE=bf16 timeout 300 python tools/diag_stream_race.py > $O/race_v24_bf16.txt 2>&1; echo "v24 bf16: $(tail -1 $O/race_v24_bf16.txt)"
+REPS=500 DTYPE=fp16 timeout 300 python tools/diag_stream_race.py > $O/race_v24_fp16.txt 2>&1; echo "v24 fp16: $(tail -1 $O/race_v24_fp16.txt)"
+timeout 200 python tools/profile_unet_ops.py --out $O/unet_ops_v24.txt > /dev/null 2>&1; head -1 $O/unet_ops_v24.txt
+grep -E "N=2560 K=320|N=5120 K=640|N=10240 K=1280|ln\(stream\)" $O/unet_ops_v24.txt
+timeout 900 python -m pytest tests/test_parity_full_gpu.py -m gpu -q -x -k "fp16 or bf16" > $O/parity_v24.log 2>&1; echo "parity rc=$?"; tail -3 $O/parity_v24.log
