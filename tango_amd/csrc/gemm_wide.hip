@@ -1,0 +1,305 @@
+// 256 x 320 LDS-DMA GEMM for the big 16-bit linears (round 2).
+//
+// Why another tile: tools/loop_probe.hip (profiles/r2_loop_probe_*.txt) takes the main loop of gemm_dma.hip apart on the GPU.
+// With its 256 x 160 tile (waves of 64 x 80) the LDS is the co-critical resource: per 128-byte k-chunk the eight waves read
+// 144 KiB of fragments and the DMA engine writes another 52 KiB, against 1280 MFMA cycles per SIMD -- the MFMA-only loop runs
+// at 1800 TF-equivalent, MFMA + fragment reads at 1690, and switching the DMA on costs another 30 %.  Doubling the tile to
+// 256 x 320 (waves of 64 x 160) cuts both per flop: fragment reads 0.45 -> 0.35 per MFMA, DMA bytes 0.33 -> 0.22 per
+// MFMA-cycle.  Measured in the probe with an epilogue attached: 9-19 % faster than the 256 x 160 ping-pong loop on the UNet's
+// linear shapes.  Layout differences to gemm_dma.hip:
+//   * 64-byte k-chunks (one MFMA k-step), FOUR stages of (256 + 320) rows x 64 B = 144 KiB, so three chunks are in flight
+//     and the ping-pong runs at chunk granularity: [ds_read 14 fragments | wait own DMAs of chunk kc+1] barrier
+//     [issue chunk kc+3 | 40 MFMAs] barrier, the two 4-wave halves one barrier out of phase;
+//   * a DMA instruction covers 16 rows x 64 B; the LDS image is lane-linear (row = lane >> 2, slot = lane & 3) and the
+//     16-byte piece is XOR-swizzled on the SOURCE side by h(row >> 2), h = {0, 3, 2, 1}, which makes the fragment reads
+//     (lane (l15, g) reads row l15, piece g) conflict-free for ds_read_b128's four lane groups (MI355X_MICROARCH.md);
+//   * its own epilogue (wide_epilogue below: bias / residual / GEGLU, arithmetic bit-identical to the other GEMM kernels),
+//     16 or 32 rows per pass through the first stages of the operand ring.
+// Linear problems only (A [M][K] row-major, W [N][Kp]); M % 256 == 0, N % 320 == 0, K a multiple of 32 elements.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "common.h"
+#include "gemm_device.h"
+
+namespace tango {
+
+
+// Epilogue of one wave's 64 x 160 accumulator block, written for this tile (gemm_epilogue_staged16's generic residual /
+// predication logic compiled into ~3000 instructions of branches and took as long as the main loop: tools trace, 21-40 us per
+// tile).  GEGLU and RES are compile-time; the arithmetic and its order are those of gemm_epilogue_staged (acc * alpha + bias
+// [+ bias2] -> activation / gate -> fp32 staging -> + residual -> * out_scale -> one rounding), so results are bit-identical.
+// Passes of 16 rows (32 for GEGLU, whose output rows are half as wide) = 320 16-byte output pieces = exactly five wave
+// iterations, no partial one.  vmcnt retires in order and counts stores: the residual pieces of pass p+1 are requested BEFORE
+// the stores of pass p are issued, so waiting for them (vmcnt <= 2 * NIT) never waits for a store.
+template <typename T, bool GEGLU, bool RES>
+__device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[10][4], const int m_base, const int n_base, const int lane,
+                                              unsigned char* stage) {
+  constexpr int TN = 10, TM = 4, NIT = 5;
+  constexpr int OC = GEGLU ? 80 : 160;                 // output columns of this wave
+  constexpr int PITCH = OC * 4 + 16;                   // fp32 staging row
+  constexpr int PPR = OC / 8;                          // 16-byte output pieces per row
+  constexpr int RPP = GEGLU ? 32 : 16;                 // rows per pass
+  constexpr int NPASS = 64 / RPP;
+  const int l15 = lane & 15, g4 = (lane >> 4) * 4;
+  const float* bias2 = p.bias2 ? p.bias2 + (int64_t)(p.step_ptr ? *p.step_ptr : 0) * p.bias2_stride : nullptr;
+  f32x4 cb[TN];
+#pragma unroll
+  for (int a = 0; a < TN; ++a) {
+    const int n = n_base + a * 16 + g4;
+    cb[a] = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias2) cb[a] += *(const f32x4*)(bias2 + n);
+  }
+  const int ocol0 = GEGLU ? (n_base >> 1) : n_base;
+  const T* Rb = (const T*)p.R;
+  T* Ob = (T*)p.out;
+  int prow[NIT], pcol[NIT];                            // (row within the pass, first output column) of this lane's piece per iteration
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = lane + it * 64;
+    prow[it] = idx / PPR;
+    pcol[it] = (idx - prow[it] * PPR) * 8;
+  }
+  u32x4 rv[2][NIT];
+  auto fetch_res = [&](const int ps, u32x4 (&dst)[NIT]) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      dst[it] = *(const u32x4*)(Rb + (int64_t)(m_base + ps * RPP + prow[it]) * p.ldr + ocol0 + pcol[it]);
+  };
+  if (RES) fetch_res(0, rv[0]);
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+    for (int bb = 0; bb < RPP / 16; ++bb) {
+      const int b = ps * (RPP / 16) + bb;
+#pragma unroll
+      for (int a = 0; a < TN; a += GEGLU ? 2 : 1) {
+        f32x4 v = acc[a][b] * p.alpha + cb[a];
+        if (GEGLU) {
+          float gt[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gt[r] = acc[a + 1][b][r] * p.alpha + cb[a + 1][r];
+          glu_gate4<T>(v, gt, p.glu_tanh);
+        } else if (p.e_act != ACT_NONE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.e_act, p.e_slope);
+        }
+        *(f32x4*)(stage + (bb * 16 + l15) * PITCH + ((GEGLU ? (a >> 1) : a) * 16 + g4) * 4) = v;
+      }
+    }
+    if (RES && ps + 1 < NPASS) fetch_res(ps + 1, rv[(ps + 1) & 1]);
+    __builtin_amdgcn_wave_barrier();
+    if (RES) {
+      // the NIT residual loads of this pass are older than the previous pass's NIT stores and the NIT loads just issued
+      if (ps == 0) { if (NPASS > 1) wait_vmcnt_lit<NIT>(); else wait_vmcnt_lit<0>(); }
+      else if (ps + 1 < NPASS) wait_vmcnt_lit<2 * NIT>();
+      else wait_vmcnt_lit<NIT>();
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const f32x4 lo = *(const f32x4*)(stage + prow[it] * PITCH + pcol[it] * 4);
+      const f32x4 hi = *(const f32x4*)(stage + prow[it] * PITCH + pcol[it] * 4 + 16);
+      float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (RES) {
+        T r8[8];
+        __builtin_memcpy(r8, &rv[ps & 1][it], 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += to_f(r8[e]);
+      }
+      if (p.out_scale != 1.f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= p.out_scale;
+      }
+      T tv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tv[e] = from_f<T>(f[e]);
+      u32x4 o;
+      __builtin_memcpy(&o, tv, 16);
+      *(u32x4*)(Ob + (int64_t)(m_base + ps * RPP + prow[it]) * p.ldo + ocol0 + pcol[it]) = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <typename T, bool GEGLU, bool RES>
+__global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, const int pp_mode, unsigned long long* __restrict__ trace) {
+  constexpr int BM = 256, BN = 320, CB = 64, NST = 4;
+  constexpr int ROWS = BM + BN, STAGE = ROWS * CB;
+  constexpr int RG = ROWS / 16;                  // 16-row groups (1 KiB) per stage: 36
+  constexpr int RGW = (RG + 7) / 8;              // DMA instructions per wave per chunk: 5 (waves 0-3) or 4 (waves 4-7)
+  constexpr int TM = 4, TN = 10;                 // wave tile 64 x 160; waves 4 (M) x 2 (N)
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // NST stages
+
+  // TANGO_WIDE_TRACE=1: wave 0 of every workgroup records 100 MHz timestamps at start / first chunk landed / loop end / end
+  unsigned long long t_start = 0, t_first = 0, t_loop = 0;
+  if (trace) t_start = __builtin_amdgcn_s_memrealtime();
+  const int NT = p.N / BN;
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // XCD x works through a contiguous range of tiles
+  }
+  const int m0 = (bid / NT) * BM, n0 = (bid % NT) * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+
+  // ---- DMA source rows: row group rg = wave + 8 i; i < 2 are activation rows (rg < 16), i >= 2 weight rows, for every wave ----
+  const int lrow = lane >> 2;
+  const int pc = (lane & 3) ^ ((4 - (lrow >> 2)) & 3);
+  const unsigned char* Ab = (const unsigned char*)p.A;
+  const unsigned char* Wb = (const unsigned char*)p.W;
+  int64_t r_base[RGW];
+#pragma unroll
+  for (int i = 0; i < RGW; ++i) {
+    const int row = (wave + 8 * i) * 16 + lrow;
+    r_base[i] = i < 2 ? ((int64_t)(m0 + row) * p.lda) * (int64_t)sizeof(T) + pc * 16
+                      : ((int64_t)(n0 + row - BM) * p.Kp) * (int64_t)sizeof(T) + pc * 16;
+  }
+  const int my_count = wave < RG - 8 * (RGW - 1) ? RGW : RGW - 1;      // wave-uniform
+  auto issue_chunk = [&](const int kc, const int st) {
+#pragma unroll
+    for (int i = 0; i < RGW; ++i) {
+      const int rg = wave + 8 * i;
+      if (rg < RG) {
+        const unsigned char* src = (i < 2 ? Ab : Wb) + r_base[i] + (int64_t)kc * CB;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dsm + st * STAGE + rg * 1024), 16, 0, 0);
+      }
+    }
+  };
+  // at most `chunks` whole chunks of this wave's DMAs may stay in flight
+  auto wait_inflight = [&](const int chunks) {
+    if (chunks <= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+    if (my_count == RGW) {
+      if (chunks == 1) wait_vmcnt_lit<RGW>();
+      else wait_vmcnt_lit<2 * RGW>();
+    } else {
+      if (chunks == 1) wait_vmcnt_lit<RGW - 1>();
+      else wait_vmcnt_lit<2 * (RGW - 1)>();
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K * (int)sizeof(T)) / CB;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int foff = l15 * CB + ((g ^ ((4 - (l15 >> 2)) & 3)) * 16);
+  const int xrow = (wm * TM * 16) * CB + foff;
+  const int wrow = (BM + wn * TN * 16) * CB + foff;
+
+  const int npro = nk < NST - 1 ? nk : NST - 1;
+  for (int c = 0; c < npro; ++c) issue_chunk(c, c);
+  const int half = pp_phase_half(wave, lane, (unsigned*)(dsm + (NST - 1) * STAGE), pp_mode);   // scratch: last stage, first DMA'd in the loop
+  wait_inflight(npro - 1);                              // chunk 0 landed
+  pp_barrier();
+  if (trace) t_first = __builtin_amdgcn_s_memrealtime();
+  if (half) pp_barrier();                               // the stagger
+  int st = 0;
+  for (int kc = 0; kc < nk; ++kc) {
+    const unsigned char* Xs = dsm + st * STAGE;
+    u32x4 wf[TN], xf[TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a) wf[a] = *(const u32x4*)(Xs + wrow + a * 16 * CB);
+#pragma unroll
+    for (int b = 0; b < TM; ++b) xf[b] = *(const u32x4*)(Xs + xrow + b * 16 * CB);
+    // this wave's DMAs of chunk kc+1 must have landed before the barrier that precedes anyone's read of that chunk;
+    // chunk kc+2 (if issued) may stay in flight
+    if (kc + 1 < nk) wait_inflight(kc + 2 < nk ? 1 : 0);
+    pp_barrier();
+    if (kc + NST - 1 < nk) issue_chunk(kc + NST - 1, st == 0 ? NST - 1 : st - 1);   // refills the stage of chunk kc-1
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) Mma<T>::run(acc[a][b], wf[a], xf[b]);
+    __builtin_amdgcn_s_setprio(0);
+    pp_barrier();
+    st = st == NST - 1 ? 0 : st + 1;
+  }
+  if (!half) pp_barrier();
+  __syncthreads();   // every wave is past its last fragment read: the operand stages become the staging area
+  if (trace) t_loop = __builtin_amdgcn_s_memrealtime();
+  wide_epilogue<T, GEGLU, RES>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, lane, dsm + wave * 10752);   // slice = max(16 rows x 656 B, 32 rows x 336 B)
+  if (trace && tid == 0) {
+    const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();      // every store of wave 0 issued ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // ... and acknowledged
+    unsigned long long* t = trace + (size_t)blockIdx.x * 5;
+    t[0] = t_start; t[1] = t_first; t[2] = t_loop; t[3] = t_issued; t[4] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+// which problems: 16-bit linear, plain / GEGLU epilogue into T, whole 256 x 320 tiles, at least NST k-chunks, and enough
+// tiles to fill the chip
+bool gemm_wide_ok(int dtype, const GemmParams& p) {
+  static const bool off = getenv("TANGO_NO_WIDE_GEMM") != nullptr;
+  if (off || dtype == DT_F32) return false;
+  const bool linear = p.mode == GATHER_1D && p.taps == 1 && p.rows_pb == p.M && p.in_mul == 1 && p.in_off == 0 && p.out_mul == 1 &&
+                      p.out_off == 0 && p.Lin >= p.M;
+  if (!linear || p.batch != 1 || p.splitk > 1 || p.a_act != ACT_NONE || p.bias_rows || p.out_f32 || p.ln_fold) return false;
+  if (p.epi != EPI_NONE && p.epi != EPI_GEGLU) return false;
+  if (p.epi == EPI_GEGLU && p.e_act != ACT_NONE) return false;
+  if (p.M % 256 != 0 || p.N % 320 != 0 || (p.K * 2) % 64 != 0 || p.K * 2 < 4 * 64) return false;
+  if (p.ldo % 8 != 0 || ((uintptr_t)p.out & 15) || (p.R && (p.ldr % 8 != 0 || ((uintptr_t)p.R & 15)))) return false;
+  if ((p.lda * 2) % 16 != 0 || (p.Kp * 2) % 16 != 0 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
+  if (((uintptr_t)p.bias & 15) || ((uintptr_t)p.bias2 & 15) || (p.bias2 && p.bias2_stride % 4 != 0)) return false;
+  static const bool force = getenv("TANGO_FORCE_DMA_GEMM") != nullptr;   // tests: exercise this kernel on small shapes
+  const long tiles = (long)(p.M / 256) * (p.N / 320);
+  return force || tiles >= 224;
+}
+
+template <typename T, bool GEGLU, bool RES>
+static int launch_wide_cfg(const GemmParams& p, hipStream_t s) {
+  constexpr int LDS = 4 * (256 + 320) * 64;
+  auto kfn = gemm_wide_kernel<T, GEGLU, RES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  static const int pp_mode = getenv("TANGO_PP_HALF") ? atoi(getenv("TANGO_PP_HALF")) : 1;   // 1: SIMD-based phase assignment
+  static const bool tracing = getenv("TANGO_WIDE_TRACE") != nullptr;                        // diagnostic: per-workgroup phase times
+  const unsigned grid = (unsigned)((p.M / 256) * (p.N / 320));
+  unsigned long long* trace = nullptr;
+  if (tracing) TANGO_HIP(hipMalloc((void**)&trace, (size_t)grid * 40));
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS, s, p, pp_mode, trace);
+  TANGO_HIP(hipGetLastError());
+  if (tracing) {
+    std::vector<unsigned long long> h((size_t)grid * 5);
+    TANGO_HIP(hipStreamSynchronize(s));
+    TANGO_HIP(hipMemcpy(h.data(), trace, (size_t)grid * 40, hipMemcpyDeviceToHost));
+    TANGO_HIP(hipFree(trace));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    double pro = 0, loop = 0, epi = 0, ack = 0;
+    for (unsigned i = 0; i < grid; ++i) {
+      const unsigned long long* t = &h[(size_t)i * 5];
+      t0 = t[0] < t0 ? t[0] : t0;
+      t1 = t[4] > t1 ? t[4] : t1;
+      pro += (double)(t[1] - t[0]); loop += (double)(t[2] - t[1]); epi += (double)(t[3] - t[2]); ack += (double)(t[4] - t[3]);
+    }
+    fprintf(stderr, "gemm_wide trace M=%d N=%d K=%d epi=%d res=%d: %u tiles, span %.1f us; per tile: prologue %.2f us, main loop %.2f us, "
+            "epilogue issue %.2f us, store drain %.2f us\n",
+            p.M, p.N, p.K, p.epi, p.R ? 1 : 0, grid, (double)(t1 - t0) * 0.01, pro / grid * 0.01, loop / grid * 0.01, epi / grid * 0.01, ack / grid * 0.01);
+  }
+  return 0;
+}
+
+template <typename T>
+static int launch_wide_t(const GemmParams& p, hipStream_t s) {
+  if (p.epi == EPI_GEGLU) return p.R ? launch_wide_cfg<T, true, true>(p, s) : launch_wide_cfg<T, true, false>(p, s);
+  return p.R ? launch_wide_cfg<T, false, true>(p, s) : launch_wide_cfg<T, false, false>(p, s);
+}
+
+int launch_gemm_wide(int dtype, const GemmParams& p, hipStream_t s) {
+  switch (dtype) {
+    case DT_F16: return launch_wide_t<f16>(p, s);
+    case DT_BF16: return launch_wide_t<bf16>(p, s);
+  }
+  TANGO_FAIL("gemm_wide: 16-bit dtypes only");
+}
+
+}  // namespace tango

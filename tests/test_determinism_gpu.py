@@ -87,6 +87,22 @@ def test_linear_repeat(lib, dtype, M, N, K, res):
            (M, N), ref, TOL[dtype], "linear %s M=%d N=%d K=%d" % (dtype, M, N, K))
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("M,N,K,res", [(57344, 320, 160, 1), (65536, 640, 2560, 0), (16384, 1280, 1280, 1), (57344, 320, 128, 0)])
+def test_wide_gemm_repeat(lib, dtype, M, N, K, res):
+    """256 x 320 ping-pong LDS-DMA GEMM (gemm_wide.hip): >= 224 tiles, k-chunk counts 4 (the minimum: prologue == whole K),
+    5, 40 and 80, with and without the residual epilogue, both 16-bit types"""
+    g = torch.Generator().manual_seed(M + N + K + res)
+    x = q(torch.randn(M, K, generator=g), dtype).cuda()
+    w = q(torch.randn(N, K, generator=g) / K ** 0.5, dtype).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    r = q(torch.randn(M, N, generator=g), dtype).cuda() if res else None
+    ref = F.linear(x, w, b)
+    ref = (ref + r if res else ref).cpu()
+    repeat(lib, lambda out: lib.tango_op_linear(DT[dtype], p(x), p(w), p(b), p(r), p(out), M, N, K, 0, 0, 0, None),
+           (M, N), ref, TOL[dtype], "wide linear %s M=%d N=%d K=%d" % (dtype, M, N, K))
+
+
 @pytest.mark.parametrize("dtype,M,C,K", [("fp16", 32768, 640, 640), ("bf16", 32768, 640, 640), ("fp16", 16384, 1280, 1280), ("fp32", 32768, 320, 512)])
 def test_persistent_gemm_geglu_repeat(lib, dtype, M, C, K):
     """LDS-DMA GEMM (gemm_dma.hip; gemm_pers.hip under TANGO_PERS_GEMM=1) with the fused GEGLU epilogue: x [M, K] @ W [8C, K] -> value * gelu(gate) [M, 4C]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmark of single engine ops through the C ABI (for rocprofv3 --pmc runs).
-usage: python tools/bench_ops.py linear M N K [reps]   |   conv B C H W Cout [reps]"""
+usage: python tools/bench_ops.py linear M N K [reps [res|nores [geglu]]]   |   conv B C H W Cout [reps]"""
 import ctypes as C
 import os
 import sys
@@ -20,10 +20,12 @@ if kind == "linear":
     x = torch.randn(M, K, device="cuda")
     w = torch.randn(N, K, device="cuda") / K ** 0.5
     b = torch.randn(N, device="cuda")
-    r = torch.randn(M, N, device="cuda")
-    out = torch.empty(M, N, device="cuda")
+    geglu = 1 if len(sys.argv) > 7 and sys.argv[7] == "geglu" else 0
+    No = N // 2 if geglu else N
+    r = torch.randn(M, No, device="cuda")
+    out = torch.empty(M, No, device="cuda")
     for _ in range(reps):
-        assert lib.tango_op_linear(1, p(x), p(w), p(b), p(r) if use_res else None, p(out), M, N, K, 0, 0, 0, None) == 0
+        assert lib.tango_op_linear(1, p(x), p(w), p(b), p(r) if use_res else None, p(out), M, N, K, 0, 0, geglu, None) == 0
 elif kind == "conv":
     B, Cc, H, W, Co = [int(v) for v in sys.argv[2:7]]
     reps = int(sys.argv[7]) if len(sys.argv) > 7 else 5

@@ -30,6 +30,66 @@ __device__ __forceinline__ void mma(f32x4& c, const u32x4& a, const u32x4& b) {
   c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
 }
 
+
+// Epilogue emulation (bit 5): the wave's accumulators go to HBM as fp16 through a per-wave LDS staging slice, 16 rows at a
+// time, so that global stores are 16-byte pieces of contiguous row segments (what gemm_epilogue_staged16 does, minus bias /
+// residual / activation).  `stg` must not alias LDS another wave may still read: callers barrier first.
+template <int TM_, int TN_>
+__device__ __forceinline__ void epilogue_emul(f32x4 (&acc)[TN_][TM_], unsigned char* stg, _Float16* out, long ldo, int row0, int col0, int lane) {
+  constexpr int WN = TN_ * 16, PITCH = WN * 2 + 16;
+  const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int b = 0; b < TM_; ++b) {
+#pragma unroll
+    for (int a = 0; a < TN_; ++a) {
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      const h4 v = h4{(_Float16)acc[a][b][0], (_Float16)acc[a][b][1], (_Float16)acc[a][b][2], (_Float16)acc[a][b][3]};
+      *(h4*)(stg + l15 * PITCH + (a * 16 + g * 4) * 2) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int PIECES = 16 * WN * 2 / 16;
+#pragma unroll
+    for (int i = lane; i < PIECES; i += 64) {
+      const int r = i / (WN / 8), c = i % (WN / 8);
+      const u32x4 v = *(const u32x4*)(stg + r * PITCH + c * 16);
+      *(u32x4*)((unsigned char*)(out + (long)(row0 + b * 16 + r) * ldo + col0) + c * 16) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// Workgroup-cooperative epilogue emulation (bit 6): in two passes, all 8 waves park half of their accumulator row-blocks in one
+// LDS tile [BM/2][BN] fp16 (row pitch BN*2 + 16), barrier, then every wave stores WHOLE tile rows (BN*2 contiguous bytes).
+template <int BM_, int BN_, int WGM, int TM_, int TN_>
+__device__ __forceinline__ void epilogue_coop(f32x4 (&acc)[TN_][TM_], unsigned char* lds, _Float16* out, long ldo, int m0, int n0, int wm,
+                                              int wcol0, int tid) {
+  constexpr int PITCH = BN_ * 2 + 16, HB = TM_ / 2, WROWS = TM_ * 16;
+  static_assert(TM_ % 2 == 0, "two passes");
+  const int lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    if (ps) __syncthreads();
+#pragma unroll
+    for (int b = 0; b < HB; ++b)
+#pragma unroll
+      for (int a = 0; a < TN_; ++a) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const f32x4 c = acc[a][ps * HB + b];
+        const h4 v = h4{(_Float16)c[0], (_Float16)c[1], (_Float16)c[2], (_Float16)c[3]};
+        *(h4*)(lds + (wm * (WROWS / 2) + b * 16 + l15) * PITCH + (wcol0 + a * 16 + g * 4) * 2) = v;
+      }
+    __syncthreads();
+    constexpr int PPR = BN_ * 2 / 16, PIECES = (BM_ / 2) * PPR;
+#pragma unroll 4
+    for (int i = tid; i < PIECES; i += 512) {
+      const int r = i / PPR, c = i % PPR;
+      const int grow = (r / (WROWS / 2)) * WROWS + ps * (WROWS / 2) + r % (WROWS / 2);
+      const u32x4 v = *(const u32x4*)(lds + r * PITCH + c * 16);
+      *(u32x4*)((unsigned char*)(out + (long)(m0 + grow) * ldo + n0) + c * 16) = v;
+    }
+  }
+}
+
 constexpr int BM = 256, BN = 160, BKB = 128, ROWS = BM + BN, STAGE = ROWS * BKB, RG = ROWS / 8, RGW = (RG + 7) / 8;
 constexpr int TM = 4, TN = 5;
 
@@ -154,6 +214,11 @@ __global__ __launch_bounds__(512, 2) void probe_kernel(const unsigned char* __re
     st = st == 2 ? 0 : st + 1;
   }
   if (PP && !half) __builtin_amdgcn_s_barrier();
+  if (ABL & 32) {
+    __syncthreads();
+    epilogue_emul<TM, TN>(acc, dsm + wave * (16 * (TN * 32 + 16)), (_Float16*)out, N, m0 + wm * 64, n0 + wn * 80, lane);
+    return;
+  }
   f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int a = 0; a < TN; ++a)
@@ -167,10 +232,17 @@ __global__ __launch_bounds__(512, 2) void probe_kernel(const unsigned char* __re
 // ---- candidate main loops: 64-byte k-chunks (one MFMA k-step per chunk), NST stages, ping-pong at chunk granularity ----
 // DMA instruction = 16 rows x 64 B; LDS image lane-linear (row = lane >> 2, slot = lane & 3) with the piece XOR-swizzled on the
 // source side by h(row >> 2), h = {0, 3, 2, 1}: conflict-free for ds_read_b128's lane groups (MI355X_MICROARCH.md, LDS table).
-template <int BM_, int BN_, int WGM, int WGN, int NST, int ABL>
-__global__ __launch_bounds__(512) void probe2_kernel(const unsigned char* __restrict__ A, const unsigned char* __restrict__ W,
-                                                     float* __restrict__ out, int M, int N, int Kbytes) {
+template <int BM_, int BN_, int WGM, int WGN, int NST, int ABL, int MINB>
+__global__ __launch_bounds__(512, MINB) void probe2_kernel(const unsigned char* __restrict__ A, const unsigned char* __restrict__ W,
+                                                     float* __restrict__ out, int M, int N, int Kbytes, int stagger) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  if (stagger > 0 && blockIdx.x < 256 * MINB) {
+    // first-round workgroups start k/8 of a tile period late (k from the block index), so that the chip's workgroups do not
+    // all read and all write HBM at the same instants; later rounds inherit the phase of the workgroup they replace
+    const unsigned long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long wait = (unsigned long)(((blockIdx.x >> 3) & 7) * stagger) >> 3;     // 10 ns units
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
   constexpr bool NO_DMA = ABL & 1, NO_RD = ABL & 2, NO_MMA = ABL & 4;
   constexpr int CB = 64, ROWS_ = BM_ + BN_, STAGE_ = ROWS_ * CB, RG_ = ROWS_ / 16, RGW_ = (RG_ + 7) / 8;
   constexpr int TM_ = BM_ / WGM / 16, TN_ = BN_ / WGN / 16;
@@ -278,6 +350,16 @@ __global__ __launch_bounds__(512) void probe2_kernel(const unsigned char* __rest
     st = st == NST - 1 ? 0 : st + 1;
   }
   if (!half) __builtin_amdgcn_s_barrier();
+  if (ABL & 32) {
+    __syncthreads();
+    epilogue_emul<TM_, TN_>(acc, dsm + wave * (16 * (TN_ * 32 + 16)), (_Float16*)out, N, m0 + wm * TM_ * 16, n0 + wn * TN_ * 16, lane);
+    return;
+  }
+  if (ABL & 64) {
+    __syncthreads();
+    epilogue_coop<BM_, BN_, WGM, TM_, TN_>(acc, dsm, (_Float16*)out, N, m0, n0, wm, wn * TN_ * 16, tid);
+    return;
+  }
   f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int a = 0; a < TN_; ++a)
@@ -287,29 +369,30 @@ __global__ __launch_bounds__(512) void probe2_kernel(const unsigned char* __rest
   if (s[0] + s[1] + s[2] + s[3] == 1234.5f) out[blockIdx.x * 512 + tid] = s[0];
 }
 
-template <int BM_, int BN_, int WGM, int WGN, int NST, int ABL>
-static void run2(const char* name, const unsigned char* A, const unsigned char* W, float* out, int M, int N, int Kb) {
+template <int BM_, int BN_, int WGM, int WGN, int NST, int ABL, int MINB = 1>
+static double run2(const char* name, const unsigned char* A, const unsigned char* W, float* out, int M, int N, int Kb, int stagger = 0) {
   constexpr int LDS = NST * (BM_ + BN_) * 64;
-  static_assert(LDS <= 160 * 1024, "LDS");
-  if (M % BM_ || N % BN_) { printf("%-58s (shape does not tile)\n", name); return; }
-  auto k = probe2_kernel<BM_, BN_, WGM, WGN, NST, ABL>;
+  static_assert(LDS <= 160 * 1024 && (!(ABL & 64) || (BM_ / 2) * (BN_ * 2 + 16) <= LDS), "LDS");
+  if (M % BM_ || N % BN_) { printf("%-58s (shape does not tile)\n", name); return 0.0; }
+  auto k = probe2_kernel<BM_, BN_, WGM, WGN, NST, ABL, MINB>;
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   const int grid = (M / BM_) * (N / BN_);
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS, 0, A, W, out, M, N, Kb);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS, 0, A, W, out, M, N, Kb, stagger);
   CHECK(hipDeviceSynchronize());
   const int reps = 10;
   CHECK(hipEventRecord(e0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS, 0, A, W, out, M, N, Kb);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS, 0, A, W, out, M, N, Kb, stagger);
   CHECK(hipEventRecord(e1));
   CHECK(hipEventSynchronize(e1));
   float ms = 0.f;
   CHECK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1000.0 / reps;
   const double tf = 2.0 * M * N * (Kb / 2.0) / (us * 1e-6) / 1e12;
-  printf("%-58s %9.1f us  (%6.0f TF-equivalent, %d workgroups)\n", name, us, tf, grid);
+  printf("%-58s %9.1f us  (%6.0f TF-equivalent, %d workgroups, stagger %d0 ns)\n", name, us, tf, grid, stagger);
+  return us * 256.0 * MINB / grid;   // us per tile period
 }
 
 template <int ABL, bool PP>
@@ -345,42 +428,35 @@ int main(int argc, char** argv) {
   float* out;
   CHECK(hipMalloc(&A, (size_t)M * Kb));
   CHECK(hipMalloc(&W, (size_t)N * Kb));
-  CHECK(hipMalloc(&out, (size_t)(M / BM) * (N / BN) * 512 * 4));
+  CHECK(hipMalloc(&out, (size_t)M * N * 2 + (size_t)(M / 128) * (N / 64) * 512 * 4));
   CHECK(hipMemset(A, 0x3c, (size_t)M * Kb));
   CHECK(hipMemset(W, 0x2c, (size_t)N * Kb));
   printf("loop probe: M=%d N=%d K=%d (fp16), tile 256x160, %d workgroups, %d chunks each; clock assumed %.2f GHz\n", M, N, Kb / 2,
          (M / BM) * (N / BN), Kb / BKB, clk);
-  run<16, false>("lock-step: full, XCD-ordered tiles", A, W, out, M, N, Kb, clk);
-  run<16 + 6, false>("lock-step: DMA + barrier only, XCD-ordered", A, W, out, M, N, Kb, clk);
-  run<16, true>("ping-pong: full, XCD-ordered tiles", A, W, out, M, N, Kb, clk);
-  run<16 + 1, true>("ping-pong: no DMA, XCD-ordered", A, W, out, M, N, Kb, clk);
-  run<16 + 6, true>("ping-pong: DMA + barrier only, XCD-ordered", A, W, out, M, N, Kb, clk);
-  run2<256, 160, 4, 2, 4, 0>("pp64 256x160 (4x2 waves of 64x80), 4 stages: full", A, W, out, M, N, Kb);
-  run2<256, 160, 4, 2, 6, 0>("pp64 256x160 (4x2 waves of 64x80), 6 stages: full", A, W, out, M, N, Kb);
-  run2<256, 160, 4, 2, 4, 1>("pp64 256x160 (4x2 waves of 64x80), 4 stages: no DMA", A, W, out, M, N, Kb);
-  run2<256, 320, 2, 4, 4, 0>("pp64 256x320 (2x4 waves of 128x80), 4 stages: full", A, W, out, M, N, Kb);
-  run2<256, 320, 2, 4, 4, 1>("pp64 256x320 (2x4 waves of 128x80), 4 stages: no DMA", A, W, out, M, N, Kb);
-  run2<256, 320, 2, 4, 4, 6>("pp64 256x320 (2x4 waves of 128x80), 4 stages: DMA only", A, W, out, M, N, Kb);
-  run2<256, 320, 2, 4, 4, 3>("pp64 256x320 (2x4 waves of 128x80), 4 stages: MFMA only", A, W, out, M, N, Kb);
-  run2<256, 320, 4, 2, 4, 0>("pp64 256x320 (4x2 waves of 64x160), 4 stages: full", A, W, out, M, N, Kb);
-  run2<512, 160, 4, 2, 3, 0>("pp64 512x160 (4x2 waves of 128x80), 3 stages: full", A, W, out, M, N, Kb);
-  run2<384, 160, 4, 2, 4, 0>("pp64 384x160 (4x2 waves of 96x80), 4 stages: full", A, W, out, M, N, Kb);
-  run2<256, 256, 2, 4, 5, 0>("pp64 256x256 (2x4 waves of 128x64), 5 stages: full", A, W, out, M, N, Kb);
-  run2<256, 256, 4, 2, 5, 0>("pp64 256x256 (4x2 waves of 64x128), 5 stages: full", A, W, out, M, N, Kb);
-  run<0, false>("lock-step: full", A, W, out, M, N, Kb, clk);
-  run<1, false>("lock-step: no DMA", A, W, out, M, N, Kb, clk);
-  run<2, false>("lock-step: no fragment reads", A, W, out, M, N, Kb, clk);
-  run<4, false>("lock-step: no MFMA", A, W, out, M, N, Kb, clk);
-  run<8, false>("lock-step: no barrier/wait", A, W, out, M, N, Kb, clk);
-  run<3, false>("lock-step: MFMA + barrier only", A, W, out, M, N, Kb, clk);
-  run<11, false>("lock-step: MFMA only", A, W, out, M, N, Kb, clk);
-  run<9, false>("lock-step: reads + MFMA (no DMA, no bar)", A, W, out, M, N, Kb, clk);
-  run<6, false>("lock-step: DMA + barrier only", A, W, out, M, N, Kb, clk);
-  run<5, false>("lock-step: reads + barrier only", A, W, out, M, N, Kb, clk);
-  run<0, true>("ping-pong: full", A, W, out, M, N, Kb, clk);
-  run<1, true>("ping-pong: no DMA", A, W, out, M, N, Kb, clk);
-  run<2, true>("ping-pong: no fragment reads", A, W, out, M, N, Kb, clk);
-  run<4, true>("ping-pong: no MFMA", A, W, out, M, N, Kb, clk);
-  run<3, true>("ping-pong: MFMA + barrier only", A, W, out, M, N, Kb, clk);
+  // with the epilogue emulation (bit 5): what a whole linear costs apart from bias / residual
+  run<16 + 32, false>("128B 256x160 lock-step 1 WG/CU + epilogue", A, W, out, M, N, Kb, clk);
+  run<16 + 32, true>("128B 256x160 ping-pong 1 WG/CU + epilogue", A, W, out, M, N, Kb, clk);
+  run<16, true>("128B 256x160 ping-pong 1 WG/CU, no epilogue", A, W, out, M, N, Kb, clk);
+  run2<256, 320, 2, 4, 4, 32>("pp64 256x320 (2x4 of 128x80) 4 st + epilogue", A, W, out, M, N, Kb);
+  run2<256, 320, 2, 4, 4, 0>("pp64 256x320 (2x4 of 128x80) 4 st, no epilogue", A, W, out, M, N, Kb);
+  {
+    const double per = run2<256, 320, 2, 4, 4, 64>("pp64 256x320 (2x4 of 128x80) 4 st + row epilogue", A, W, out, M, N, Kb);
+    run2<256, 320, 2, 4, 4, 64>("  ... staggered by 1 tile period", A, W, out, M, N, Kb, (int)(per * 100));
+    run2<256, 320, 2, 4, 4, 64>("  ... staggered by 1/2 tile period", A, W, out, M, N, Kb, (int)(per * 50));
+    run2<256, 320, 2, 4, 4, 32>("  ... per-wave epilogue, staggered by 1 period", A, W, out, M, N, Kb, (int)(per * 100));
+  }
+  run2<256, 320, 4, 2, 4, 64>("pp64 256x320 (4x2 of 64x160) 4 st + row epilogue", A, W, out, M, N, Kb);
+  run2<256, 160, 4, 2, 6, 64, 1>("pp64 256x160 (4x2 of 64x80) 6 st, 1 WG/CU + row epilogue", A, W, out, M, N, Kb);
+  {
+    const double per = run2<256, 160, 4, 2, 3, 64, 2>("pp64 256x160 (4x2 of 64x80) 3 st, 2 WG/CU + row epilogue", A, W, out, M, N, Kb);
+    run2<256, 160, 4, 2, 3, 64, 2>("  ... staggered by 1 tile period", A, W, out, M, N, Kb, (int)(per * 100));
+  }
+  run2<256, 128, 4, 2, 3, 32, 2>("pp64 256x128 (4x2 of 64x64) 3 st, 2 WG/CU + epilogue", A, W, out, M, N, Kb);
+  run2<256, 128, 4, 2, 3, 0, 2>("pp64 256x128 (4x2 of 64x64) 3 st, 2 WG/CU, no epilogue", A, W, out, M, N, Kb);
+  run2<256, 128, 4, 2, 6, 32, 1>("pp64 256x128 (4x2 of 64x64) 6 st, 1 WG/CU + epilogue", A, W, out, M, N, Kb);
+  run2<128, 128, 2, 4, 3, 32, 3>("pp64 128x128 (2x4 of 64x32) 3 st, 3 WG/CU + epilogue", A, W, out, M, N, Kb);
+  run2<256, 160, 4, 2, 4, 32, 1>("pp64 256x160 (4x2 of 64x80) 4 st, 1 WG/CU + epilogue", A, W, out, M, N, Kb);
+  run2<256, 160, 4, 2, 3, 32, 2>("pp64 256x160 (4x2 of 64x80) 3 st, 2 WG/CU + epilogue", A, W, out, M, N, Kb);
+  run2<256, 160, 4, 2, 3, 0, 2>("pp64 256x160 (4x2 of 64x80) 3 st, 2 WG/CU, no epilogue", A, W, out, M, N, Kb);
   return 0;
 }
