@@ -157,6 +157,11 @@ int tango_op_linear(int dtype, const float* x, const float* w, const float* bias
                     int N, int K, int a_act, int e_act, int geglu, void* stream);
 int tango_op_linear_ln(int dtype, const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
                        const float* residual, float* out, int M, int N, int K, int geglu, float eps, void* stream);
+/* fused self-attention projection as the engine runs it (reference: diffusers attention_processor.py Attention.to_q/to_k/to_v on
+   LayerNorm(x), transformer_2d BasicTransformerBlock.norm1): q | k row-major into out_qk [B*S, 2C], v TRANSPOSED into out_vt
+   [B][C][S]; gamma == NULL skips the LayerNorm */
+int tango_op_linear_qkv(int dtype, const float* x, const float* w, const float* gamma, const float* beta, float* out_qk,
+                        float* out_vt, int B, int S, int C, int K, float eps, void* stream);
 int tango_op_conv1d(int dtype, const float* x, const float* w, const float* bias, const float* residual, float* out, int B,
                     int Cin, int L, int Cout, int k, int dilation, int a_act, float a_slope, int e_act, float e_slope, void* stream);
 int tango_op_conv_transpose1d(int dtype, const float* x, const float* w, const float* bias, float* out, int B, int Cin, int L,

@@ -100,8 +100,8 @@ struct Builder {
     if (o.ln) {
       GemmParams q = p;
       q.W = w.Wln; q.bias = w.bln; q.ln_fold = 1; q.ln_eps = o.ln->eps; q.wsum = w.wsum;
-      if (w.Wln && linear_stream_ok(dt, q)) {
-        gemm(q, "linear+ln(stream)");
+      if (w.Wln && (linear_stream_ok(dt, q) || gemm_wide_ok(dt, q))) {
+        gemm(q, gemm_wide_ok(dt, q) ? "linear+ln(wide)" : "linear+ln(stream)");
         return;
       }
       // fallback: materialise LayerNorm(x), then the plain GEMM

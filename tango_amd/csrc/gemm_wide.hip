@@ -25,6 +25,8 @@
 
 namespace tango {
 
+constexpr int WIDE_STAGE_BYTES = 11520;   // per-wave staging: max(16 rows x 656 B, 32 rows x 336 B, 80 columns x 144 B); 1280 B of constants follow
+
 
 // Epilogue of one wave's 64 x 160 accumulator block, written for this tile (gemm_epilogue_staged16's generic residual /
 // predication logic compiled into ~3000 instructions of branches and took as long as the main loop: tools trace, 21-40 us per
@@ -33,9 +35,32 @@ namespace tango {
 // Passes of 16 rows (32 for GEGLU, whose output rows are half as wide) = 320 16-byte output pieces = exactly five wave
 // iterations, no partial one.  vmcnt retires in order and counts stores: the residual pieces of pass p+1 are requested BEFORE
 // the stores of pass p are issued, so waiting for them (vmcnt <= 2 * NIT) never waits for a store.
-template <typename T, bool GEGLU, bool RES>
-__device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[10][4], const int m_base, const int n_base, const int lane,
-                                              unsigned char* stage) {
+// one accumulator quad -> pre-activation values: acc * alpha + bias, or the folded-LayerNorm form rstd * (acc - mean * wsum) + bias
+// (cst points at this quad's bias; its wsum sits 160 floats further)
+template <bool LN>
+__device__ __forceinline__ f32x4 wide_col_value(const f32x4 av, const float mean, const float rstd, const float alpha, const float* cst) {
+  const f32x4 cbv = *(const f32x4*)cst;
+  f32x4 v;
+  if (LN) {
+    const f32x4 cwv = *(const f32x4*)(cst + 160);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t;
+      asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(t) : "v"(mean), "v"(cwv[r]), "v"(av[r]));
+      v[r] = rstd * t + cbv[r];
+    }
+  } else {
+    v = av * alpha + cbv;
+  }
+  return v;
+}
+
+// LN: folded LayerNorm (see linear_stream.hip): y = rstd[m] * (acc - mean[m] * wsum[n]) + b'[n] with the row statistics the
+// main loop accumulated; acc - mean * wsum is the single-instruction form that linear_stream.hip's race notes call for.
+// The per-column constants (bias [+ bias2], wsum) sit in LDS behind the staging rows, not in 80 VGPRs.
+template <typename T, bool GEGLU, bool RES, bool LN>
+__device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[10][4], const float (&mean)[4], const float (&rstd)[4],
+                                              const int m_base, const int n_base, const int lane, unsigned char* stage) {
   constexpr int TN = 10, TM = 4, NIT = 5;
   constexpr int OC = GEGLU ? 80 : 160;                 // output columns of this wave
   constexpr int PITCH = OC * 4 + 16;                   // fp32 staging row
@@ -44,13 +69,14 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
   constexpr int NPASS = 64 / RPP;
   const int l15 = lane & 15, g4 = (lane >> 4) * 4;
   const float* bias2 = p.bias2 ? p.bias2 + (int64_t)(p.step_ptr ? *p.step_ptr : 0) * p.bias2_stride : nullptr;
-  f32x4 cb[TN];
-#pragma unroll
-  for (int a = 0; a < TN; ++a) {
-    const int n = n_base + a * 16 + g4;
-    cb[a] = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-    if (bias2) cb[a] += *(const f32x4*)(bias2 + n);
+  float* const cst = (float*)(stage + WIDE_STAGE_BYTES);       // [bias 160 | wsum 160]
+  if (lane < 40) {
+    f32x4 bv = p.bias ? *(const f32x4*)(p.bias + n_base + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias2) bv += *(const f32x4*)(bias2 + n_base + lane * 4);
+    *(f32x4*)(cst + lane * 4) = bv;
+    if (LN) *(f32x4*)(cst + 160 + lane * 4) = *(const f32x4*)(p.wsum + n_base + lane * 4);
   }
+  __builtin_amdgcn_wave_barrier();
   const int ocol0 = GEGLU ? (n_base >> 1) : n_base;
   const T* Rb = (const T*)p.R;
   T* Ob = (T*)p.out;
@@ -75,15 +101,11 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
       const int b = ps * (RPP / 16) + bb;
 #pragma unroll
       for (int a = 0; a < TN; a += GEGLU ? 2 : 1) {
-        f32x4 v = acc[a][b] * p.alpha + cb[a];
+        f32x4 v = wide_col_value<LN>(acc[a][b], mean[b], rstd[b], p.alpha, cst + a * 16 + g4);
         if (GEGLU) {
-          float gt[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) gt[r] = acc[a + 1][b][r] * p.alpha + cb[a + 1][r];
+          const f32x4 gv = wide_col_value<LN>(acc[a + 1][b], mean[b], rstd[b], p.alpha, cst + (a + 1) * 16 + g4);
+          const float gt[4] = {gv[0], gv[1], gv[2], gv[3]};
           glu_gate4<T>(v, gt, p.glu_tanh);
-        } else if (p.e_act != ACT_NONE) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.e_act, p.e_slope);
         }
         *(f32x4*)(stage + (bb * 16 + l15) * PITCH + ((GEGLU ? (a >> 1) : a) * 16 + g4) * 4) = v;
       }
@@ -122,7 +144,73 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
   }
 }
 
-template <typename T, bool GEGLU, bool RES>
+
+// EPI_VT tiles that lie in the V projection (n0 >= vt_n0): the wave's 64 rows x 160 columns go out TRANSPOSED,
+//   vt[((m / vt_S) * (N - vt_n0) + (n - vt_n0)) * vt_ld + (m % vt_S)],
+// through an LDS transpose in T: two passes of 80 columns x 64 rows (row pitch 144 B), then 16-byte pieces along the sequence
+// axis -> 128-byte contiguous runs per column per wave (the streaming kernel stores these 2 bytes at a time).
+template <typename T, bool LN>
+__device__ __forceinline__ void wide_epilogue_vt(const GemmParams& p, f32x4 (&acc)[10][4], const float (&mean)[4], const float (&rstd)[4],
+                                                 const int m_base, const int n_base, const int lane, unsigned char* stage) {
+  constexpr int TN = 10, TM = 4, CPITCH = 64 * 2 + 16;
+  const int l15 = lane & 15, g4 = (lane >> 4) * 4;
+  float* const cst = (float*)(stage + WIDE_STAGE_BYTES);
+  if (lane < 40) {
+    *(f32x4*)(cst + lane * 4) = p.bias ? *(const f32x4*)(p.bias + n_base + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (LN) *(f32x4*)(cst + 160 + lane * 4) = *(const f32x4*)(p.wsum + n_base + lane * 4);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int bb = m_base / p.vt_S, s0 = m_base - bb * p.vt_S;
+  T* const vbase = (T*)p.vt + ((int64_t)bb * (p.N - p.vt_n0) + (n_base - p.vt_n0)) * p.vt_ld + s0;
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+    for (int al = 0; al < TN / 2; ++al) {
+      const int a = ps * (TN / 2) + al;
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const f32x4 v = wide_col_value<LN>(acc[a][b], mean[b], rstd[b], p.alpha, cst + a * 16 + g4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *(T*)(stage + (al * 16 + g4 + r) * CPITCH + (b * 16 + l15) * 2) = from_f<T>(v[r]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 10; ++it) {
+      const int idx = lane + it * 64, col = idx >> 3, pc = idx & 7;
+      const u32x4 o = *(const u32x4*)(stage + col * CPITCH + pc * 16);
+      *(u32x4*)(vbase + (int64_t)(ps * 80 + col) * p.vt_ld + pc * 8) = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// LayerNorm statistics of 8 stored elements (see linear_stream.hip: frag_stats)
+template <typename T> __device__ __forceinline__ void wide_frag_stats(const u32x4& v, float& s, float& q) {
+  if constexpr (__is_same(T, f16)) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const f16x8 h = __builtin_bit_cast(f16x8, v);
+    const h2 one = h2{(_Float16)1.f, (_Float16)1.f};
+    const h2 p0 = __builtin_shufflevector(h, h, 0, 1), p1 = __builtin_shufflevector(h, h, 2, 3);
+    const h2 p2 = __builtin_shufflevector(h, h, 4, 5), p3 = __builtin_shufflevector(h, h, 6, 7);
+    s = __builtin_amdgcn_fdot2(p0, one, s, false); q = __builtin_amdgcn_fdot2(p0, p0, q, false);
+    s = __builtin_amdgcn_fdot2(p1, one, s, false); q = __builtin_amdgcn_fdot2(p1, p1, q, false);
+    s = __builtin_amdgcn_fdot2(p2, one, s, false); q = __builtin_amdgcn_fdot2(p2, p2, q, false);
+    s = __builtin_amdgcn_fdot2(p3, one, s, false); q = __builtin_amdgcn_fdot2(p3, p3, q, false);
+  } else {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const bf16x8 h = __builtin_bit_cast(bf16x8, v);
+    const b2 one = b2{(__bf16)1.f, (__bf16)1.f};
+    const b2 p0 = __builtin_shufflevector(h, h, 0, 1), p1 = __builtin_shufflevector(h, h, 2, 3);
+    const b2 p2 = __builtin_shufflevector(h, h, 4, 5), p3 = __builtin_shufflevector(h, h, 6, 7);
+    s = __builtin_amdgcn_fdot2_f32_bf16(p0, one, s, false); q = __builtin_amdgcn_fdot2_f32_bf16(p0, p0, q, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(p1, one, s, false); q = __builtin_amdgcn_fdot2_f32_bf16(p1, p1, q, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(p2, one, s, false); q = __builtin_amdgcn_fdot2_f32_bf16(p2, p2, q, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(p3, one, s, false); q = __builtin_amdgcn_fdot2_f32_bf16(p3, p3, q, false);
+  }
+}
+
+template <typename T, bool GEGLU, bool RES, bool LN, bool VT>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, const int pp_mode, unsigned long long* __restrict__ trace) {
   constexpr int BM = 256, BN = 320, CB = 64, NST = 4;
   constexpr int ROWS = BM + BN, STAGE = ROWS * CB;
@@ -186,6 +274,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
 #pragma unroll
     for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  float ssum[TM] = {0.f, 0.f, 0.f, 0.f}, ssq[TM] = {0.f, 0.f, 0.f, 0.f};
   const int nk = (p.K * (int)sizeof(T)) / CB;
   const int l15 = lane & 15, g = lane >> 4;
   const int foff = l15 * CB + ((g ^ ((4 - (l15 >> 2)) & 3)) * 16);
@@ -213,6 +302,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
     pp_barrier();
     if (kc + NST - 1 < nk) issue_chunk(kc + NST - 1, st == 0 ? NST - 1 : st - 1);   // refills the stage of chunk kc-1
     __builtin_amdgcn_s_setprio(1);
+    if (LN) {
+      // row statistics from the activation fragments this wave holds anyway (both column halves compute them: 32 VALU
+      // instructions per chunk next to 40 MFMAs)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) wide_frag_stats<T>(xf[b], ssum[b], ssq[b]);
+    }
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -224,7 +319,22 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
   if (!half) pp_barrier();
   __syncthreads();   // every wave is past its last fragment read: the operand stages become the staging area
   if (trace) t_loop = __builtin_amdgcn_s_memrealtime();
-  wide_epilogue<T, GEGLU, RES>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, lane, dsm + wave * 10752);   // slice = max(16 rows x 656 B, 32 rows x 336 B)
+  float mean[TM] = {0.f, 0.f, 0.f, 0.f}, rstd[TM] = {1.f, 1.f, 1.f, 1.f};
+  if (LN) {
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      float sm = ssum[b], sq = ssq[b];
+      sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+      sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+      const float mu = sm / (float)p.K;
+      float var = sq / (float)p.K - mu * mu;
+      var = var < 0.f ? 0.f : var;
+      mean[b] = mu; rstd[b] = rsqrtf(var + p.ln_eps);
+    }
+  }
+  unsigned char* const slice = dsm + wave * (WIDE_STAGE_BYTES + 1280);
+  if (VT && n0 >= p.vt_n0) wide_epilogue_vt<T, LN>(p, acc, mean, rstd, m0 + wm * TM * 16, n0 + wn * TN * 16, lane, slice);
+  else wide_epilogue<T, GEGLU, RES, LN>(p, acc, mean, rstd, m0 + wm * TM * 16, n0 + wn * TN * 16, lane, slice);
   if (trace && tid == 0) {
     const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();      // every store of wave 0 issued ...
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // ... and acknowledged
@@ -240,9 +350,16 @@ bool gemm_wide_ok(int dtype, const GemmParams& p) {
   if (off || dtype == DT_F32) return false;
   const bool linear = p.mode == GATHER_1D && p.taps == 1 && p.rows_pb == p.M && p.in_mul == 1 && p.in_off == 0 && p.out_mul == 1 &&
                       p.out_off == 0 && p.Lin >= p.M;
-  if (!linear || p.batch != 1 || p.splitk > 1 || p.a_act != ACT_NONE || p.bias_rows || p.out_f32 || p.ln_fold) return false;
-  if (p.epi != EPI_NONE && p.epi != EPI_GEGLU) return false;
-  if (p.epi == EPI_GEGLU && p.e_act != ACT_NONE) return false;
+  if (!linear || p.batch != 1 || p.splitk > 1 || p.a_act != ACT_NONE || p.bias_rows || p.out_f32) return false;
+  if (p.ln_fold && (!p.wsum || ((uintptr_t)p.wsum & 15) || p.alpha != 1.f)) return false;
+  if (p.epi != EPI_NONE && p.epi != EPI_GEGLU && p.epi != EPI_VT) return false;
+  if (p.epi == EPI_VT && (p.R || p.bias2 || p.vt_n0 % 320 != 0 || p.vt_S % 256 != 0 || p.vt_ld % 8 != 0 || ((uintptr_t)p.vt & 15))) return false;
+  // folded LayerNorm: measured against the alternatives on one box -- K = 320 rows stay on the streaming kernel, and for the
+  // GEGLU shapes (N = 8 C) the separate LayerNorm kernel + plain wide GEMM is as fast or faster (row statistics cost 32 VALU
+  // instructions per k-chunk inside the MFMA phase); the narrow projections (N <= 3 C) gain 25-30 %
+  static const bool vt320 = getenv("TANGO_WIDE_VT320") != nullptr;       // experiment switch: level-0 q | k | v^T projection too
+  if (p.ln_fold && (p.epi == EPI_GEGLU || (p.K < 640 && !(vt320 && p.epi == EPI_VT)))) return false;
+  if (p.e_act != ACT_NONE) return false;            // (an inlined activation switch per element bloated this kernel 10x: not supported here)
   if (p.M % 256 != 0 || p.N % 320 != 0 || (p.K * 2) % 64 != 0 || p.K * 2 < 4 * 64) return false;
   if (p.ldo % 8 != 0 || ((uintptr_t)p.out & 15) || (p.R && (p.ldr % 8 != 0 || ((uintptr_t)p.R & 15)))) return false;
   if ((p.lda * 2) % 16 != 0 || (p.Kp * 2) % 16 != 0 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
@@ -252,10 +369,10 @@ bool gemm_wide_ok(int dtype, const GemmParams& p) {
   return force || tiles >= 224;
 }
 
-template <typename T, bool GEGLU, bool RES>
+template <typename T, bool GEGLU, bool RES, bool LN, bool VT = false>
 static int launch_wide_cfg(const GemmParams& p, hipStream_t s) {
   constexpr int LDS = 4 * (256 + 320) * 64;
-  auto kfn = gemm_wide_kernel<T, GEGLU, RES>;
+  auto kfn = gemm_wide_kernel<T, GEGLU, RES, LN, VT>;
   static bool attr_set = false;
   if (!attr_set) {
     TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -290,8 +407,13 @@ static int launch_wide_cfg(const GemmParams& p, hipStream_t s) {
 
 template <typename T>
 static int launch_wide_t(const GemmParams& p, hipStream_t s) {
-  if (p.epi == EPI_GEGLU) return p.R ? launch_wide_cfg<T, true, true>(p, s) : launch_wide_cfg<T, true, false>(p, s);
-  return p.R ? launch_wide_cfg<T, false, true>(p, s) : launch_wide_cfg<T, false, false>(p, s);
+  if (p.epi == EPI_VT) return p.ln_fold ? launch_wide_cfg<T, false, false, true, true>(p, s) : launch_wide_cfg<T, false, false, false, true>(p, s);
+  if (p.ln_fold) {
+    if (p.epi == EPI_GEGLU) return p.R ? launch_wide_cfg<T, true, true, true>(p, s) : launch_wide_cfg<T, true, false, true>(p, s);
+    return p.R ? launch_wide_cfg<T, false, true, true>(p, s) : launch_wide_cfg<T, false, false, true>(p, s);
+  }
+  if (p.epi == EPI_GEGLU) return p.R ? launch_wide_cfg<T, true, true, false>(p, s) : launch_wide_cfg<T, true, false, false>(p, s);
+  return p.R ? launch_wide_cfg<T, false, true, false>(p, s) : launch_wide_cfg<T, false, false, false>(p, s);
 }
 
 int launch_gemm_wide(int dtype, const GemmParams& p, hipStream_t s) {

@@ -178,7 +178,7 @@ int tango_op_linear_ln(int dt, const float* x, const float* w, const float* bias
   p.out = ot; p.ldo = No; p.R = rt; p.ldr = No; p.epi = geglu ? EPI_GEGLU : EPI_NONE;
   p.ln_fold = 1; p.ln_eps = eps; p.wsum = ws;
   TANGO_TRY(gemm_init());
-  if (linear_stream_ok(dt, p)) {
+  if (linear_stream_ok(dt, p) || gemm_wide_ok(dt, p)) {
     TANGO_TRY(launch_gemm(dt, p, s));
   } else {
     void* nt = sc.get((size_t)M * K * esz);
@@ -188,6 +188,51 @@ int tango_op_linear_ln(int dt, const float* x, const float* w, const float* bias
     TANGO_TRY(launch_gemm(dt, p, s));
   }
   TANGO_TRY(to_f32(dt, ot, No, out, M, No, s));
+  TANGO_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int tango_op_linear_qkv(int dt, const float* x, const float* w, const float* gamma, const float* beta, float* out_qk, float* out_vt,
+                        int B, int S, int C, int K, float eps, void* stream) {
+  // the self-attention projection of the engine: [LayerNorm](x [B*S, K]) @ Wqkv^T [3C, K] (no bias); q | k -> out_qk [B*S, 2C],
+  // v -> out_vt [B][C][S] (EPI_VT).  gamma == nullptr: no LayerNorm.  Folded LN when a kernel takes it, else LN + GEMM.
+  hipStream_t s = (hipStream_t)stream;
+  const size_t esz = dtype_size(dt);
+  Scratch sc;
+  const int M = B * S, N = 3 * C;
+  void* xt = sc.get((size_t)M * K * esz);
+  void* wt = sc.get((size_t)N * K * esz);
+  void* wl = sc.get((size_t)N * K * esz);
+  void* qk = sc.get((size_t)M * 2 * C * esz);
+  void* vt = sc.get((size_t)B * C * S * esz);
+  float* bl = (float*)sc.get((size_t)N * 4);
+  float* ws = (float*)sc.get((size_t)N * 4);
+  if (!xt || !wt || !wl || !qk || !vt || !bl || !ws) TANGO_FAIL("op_linear_qkv: alloc");
+  TANGO_TRY(launch_cast_rows(dt, x, xt, K, M, K, s));
+  TANGO_TRY(launch_pack(dt, w, wt, N, 1, K, K, 0, 1, K, 0, s));
+  GemmParams p;
+  p.A = xt; p.lda = K; p.W = wt; p.Kp = K; p.bias = nullptr; p.M = M; p.N = N; p.K = K; p.Cin = K;
+  p.mode = GATHER_1D; p.rows_pb = M; p.Lin = M; p.Lout = M;
+  p.out = qk; p.ldo = 2 * C; p.epi = EPI_VT; p.vt = vt; p.vt_n0 = 2 * C; p.vt_S = S; p.vt_ld = S;
+  TANGO_TRY(gemm_init());
+  if (gamma) {
+    TANGO_TRY(launch_fold_ln(dt, wt, K, gamma, beta, nullptr, wl, bl, ws, N, K, s));
+    GemmParams q = p;
+    q.W = wl; q.bias = bl; q.ln_fold = 1; q.ln_eps = eps; q.wsum = ws;
+    if (linear_stream_ok(dt, q) || gemm_wide_ok(dt, q)) {
+      TANGO_TRY(launch_gemm(dt, q, s));
+    } else {
+      void* nt = sc.get((size_t)M * K * esz);
+      if (!nt) TANGO_FAIL("op_linear_qkv: alloc");
+      TANGO_TRY(launch_layernorm(dt, xt, K, nt, K, gamma, beta, M, K, eps, s));
+      p.A = nt;
+      TANGO_TRY(launch_gemm(dt, p, s));
+    }
+  } else {
+    TANGO_TRY(launch_gemm(dt, p, s));
+  }
+  TANGO_TRY(to_f32(dt, qk, 2 * C, out_qk, M, 2 * C, s));
+  TANGO_TRY(to_f32(dt, vt, S, out_vt, B * C, S, s));
   TANGO_HIP(hipStreamSynchronize(s));
   return 0;
 }

@@ -103,6 +103,67 @@ def test_wide_gemm_repeat(lib, dtype, M, N, K, res):
            (M, N), ref, TOL[dtype], "wide linear %s M=%d N=%d K=%d" % (dtype, M, N, K))
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("M,N,K,geglu,res,mean", [(57344, 320, 320, 0, 0, 0.7), (32768, 2560, 320, 1, 0, 0.7), (16384, 1280, 1280, 0, 0, -0.3),
+                                                  (57344, 320, 640, 0, 1, 6.0)])
+def test_wide_gemm_ln_repeat(lib, dtype, M, N, K, geglu, res, mean):
+    """folded LayerNorm on the 256 x 320 GEMM (row statistics from the activation fragments in the main loop, per-column
+    constants through LDS): plain / GEGLU / residual epilogues, K = 1280 (no streaming-kernel equivalent), rows with |mean| >> std"""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = q(torch.randn(M, K, generator=g) * (0.5 if mean > 3 else 1.3) + mean, dtype).cuda()
+    w = q(torch.randn(N, K, generator=g) / K ** 0.5, dtype).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    ga, be = (1 + 0.2 * torch.randn(K, generator=g)).cuda(), (0.3 * torch.randn(K, generator=g)).cuda()
+    No = N // 2 if geglu else N
+    r = q(torch.randn(M, No, generator=g), dtype).cuda() if res else None
+    h = F.linear(F.layer_norm(x, (K,), ga, be, 1e-5), w, b)
+    if geglu:
+        v, gt = h.chunk(2, dim=-1)
+        h = v * F.gelu(gt)
+    ref = (h + r if res else h).cpu()
+    del h
+    tol = 2 * TOL[dtype] * (4 if mean > 3 else 1)      # x is stored in T: |mean| / std = 12 amplifies its rounding
+    repeat(lib, lambda out: lib.tango_op_linear_ln(DT[dtype], p(x), p(w), p(b), p(ga), p(be), p(r), p(out), M, N, K, geglu,
+                                                   C.c_float(1e-5), None),
+           (M, No), ref, tol, "wide linear_ln %s M=%d N=%d K=%d" % (dtype, M, N, K))
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16", "fp32"])
+@pytest.mark.parametrize("B,S,Ch,K,ln", [(16, 4096, 320, 320, 1),     # level 0: streaming kernel (K = 320 rows), scalar V^T stores
+                                        (64, 1024, 640, 640, 1),     # level 1: wide GEMM, folded LN, LDS-transposed V^T tiles
+                                        (64, 256, 1280, 1280, 1),    # level 2: wide GEMM with folded LN at K = 1280
+                                        (64, 1024, 640, 640, 0),     # wide GEMM, no LayerNorm
+                                        (3, 200, 64, 96, 1)])        # small / ragged: tile kernels, LN kernel + GEMM fallback
+def test_linear_qkv_vt_repeat(lib, dtype, B, S, Ch, K, ln):
+    """fused q | k | v^T projection (EPI_VT) through every kernel that implements it"""
+    if dtype == "fp32" and B * S > 20000:
+        pytest.skip("fp32 runs the generic kernels: covered by the small case")
+    g = torch.Generator().manual_seed(B + S + Ch + K)
+    x = q(torch.randn(B * S, K, generator=g) * 1.2 + 0.4, dtype).cuda()
+    w = q(torch.randn(3 * Ch, K, generator=g) / K ** 0.5, dtype).cuda()
+    ga, be = (1 + 0.2 * torch.randn(K, generator=g)).cuda(), (0.3 * torch.randn(K, generator=g)).cuda()
+    h = F.linear(F.layer_norm(x, (K,), ga, be, 1e-5) if ln else x, w)
+    ref_qk = h[:, :2 * Ch].cpu()
+    ref_vt = h[:, 2 * Ch:].reshape(B, S, Ch).transpose(1, 2).contiguous().cpu()
+    del h
+    first = None
+    for rep in range(REPS):
+        oqk = torch.zeros(B * S, 2 * Ch, device="cuda")
+        ovt = torch.zeros(B, Ch, S, device="cuda")
+        rc = lib.tango_op_linear_qkv(DT[dtype], p(x), p(w), p(ga) if ln else None, p(be) if ln else None, p(oqk), p(ovt), B, S, Ch, K,
+                                     C.c_float(1e-5), None)
+        assert rc == 0, lib.tango_last_error().decode()
+        if first is None:
+            first = (oqk, ovt)
+            scale = ref_qk.abs().max().item()
+            e1 = ((oqk.cpu() - ref_qk).abs().max() / scale).item()
+            e2 = ((ovt.cpu() - ref_vt).abs().max() / scale).item()
+            print("qkv %s B=%d S=%d C=%d K=%d ln=%d: rel err qk %.3e vt %.3e" % (dtype, B, S, Ch, K, ln, e1, e2))
+            assert e1 <= 2 * TOL[dtype] and e2 <= 2 * TOL[dtype]
+        else:
+            assert torch.equal(oqk, first[0]) and torch.equal(ovt, first[1]), "repetition %d differs" % rep
+
+
 @pytest.mark.parametrize("dtype,M,C,K", [("fp16", 32768, 640, 640), ("bf16", 32768, 640, 640), ("fp16", 16384, 1280, 1280), ("fp32", 32768, 320, 512)])
 def test_persistent_gemm_geglu_repeat(lib, dtype, M, C, K):
     """LDS-DMA GEMM (gemm_dma.hip; gemm_pers.hip under TANGO_PERS_GEMM=1) with the fused GEGLU epilogue: x [M, K] @ W [8C, K] -> value * gelu(gate) [M, 4C]
