@@ -348,7 +348,7 @@ static int launch_halo_cfg(const GemmParams& p, const unsigned char* zero_page, 
   const int tiles = (p.M / 256) * (p.N / BN);
   static const bool no_stage = getenv("TANGO_NO_STAGED_EPILOGUE") != nullptr;   // experiment switch
   const int staged = (!no_stage && epilogue_can_stage<T>(p)) ? 1 : 0;
-  static const int pp_mode = getenv("TANGO_PP_HALF") ? atoi(getenv("TANGO_PP_HALF")) : 1;
+  static const int pp_mode = getenv("TANGO_PP_HALF") ? atoi(getenv("TANGO_PP_HALF")) : 0;   // 0: waves w, w + 4 (one workgroup per CU: they share a SIMD, tools/simd_probe); 1: read HW_ID (+1 us per tile)
   hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(512), lds, s, p, zero_page, g.SR, g.nseg, abytes, abl, staged, pp_mode);
   TANGO_HIP(hipGetLastError());
   return 0;

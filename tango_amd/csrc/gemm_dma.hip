@@ -224,7 +224,7 @@ static int launch_dma_cfg(const GemmParams& p, hipStream_t s) {
   const int MT = (p.M + 255) / 256, NT = (p.N + BN - 1) / BN;
   static const bool no_stage = getenv("TANGO_NO_STAGED_EPILOGUE") != nullptr;   // experiment switch
   const int staged = (!no_stage && MODE != MODE_CONV1D && epilogue_can_stage<T>(p)) ? 1 : 0;
-  static const int pp_mode = getenv("TANGO_PP_HALF") ? atoi(getenv("TANGO_PP_HALF")) : 1;   // 1: SIMD-based phase assignment
+  static const int pp_mode = getenv("TANGO_PP_HALF") ? atoi(getenv("TANGO_PP_HALF")) : 0;   // 0: waves w, w + 4 (one workgroup per CU: they share a SIMD, tools/simd_probe); 1: read HW_ID (+1 us per tile)
   hipLaunchKernelGGL(kfn, dim3((unsigned)(MT * NT)), dim3(512), LDS, s, p, (const unsigned char*)g_zero_page, staged, pp_mode);
   TANGO_HIP(hipGetLastError());
   return 0;

@@ -378,7 +378,7 @@ static int launch_wide_cfg(const GemmParams& p, hipStream_t s) {
     TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
-  static const int pp_mode = getenv("TANGO_PP_HALF") ? atoi(getenv("TANGO_PP_HALF")) : 1;   // 1: SIMD-based phase assignment
+  static const int pp_mode = getenv("TANGO_PP_HALF") ? atoi(getenv("TANGO_PP_HALF")) : 0;   // 0: waves w, w + 4 (one workgroup per CU: they share a SIMD, tools/simd_probe); 1: read HW_ID (+1 us per tile)
   static const bool tracing = getenv("TANGO_WIDE_TRACE") != nullptr;                        // diagnostic: per-workgroup phase times
   const unsigned grid = (unsigned)((p.M / 256) * (p.N / 320));
   unsigned long long* trace = nullptr;
