@@ -1,0 +1,278 @@
+// 3x3 / stride 1 / pad 1 convolution with halo reuse on the 256-pixel x 320-channel tile (round 2): conv_halo.hip's algorithm
+// on gemm_wide.hip's tile, for the 16-bit engines.
+//
+// Why: tools/loop_probe.hip shows the 256 x 160 / 128-byte-chunk main loop is co-limited by LDS traffic (fragment reads +
+// DMA writes) rather than by the MFMA pipe; waves of 64 x 160 need 0.35 fragment reads per MFMA instead of 0.45, and a
+// workgroup that covers 320 output channels stages each activation halo once for twice the work.  The level-0 convolutions
+// (N = 320) become single-column tilings: no second workgroup re-stages the same halo.
+//
+// Layout: 64-byte channel chunks (one MFMA k-step).  LDS = two halo buffers (chunk cc, cc+1; up to 480 halo pixels x 64 B
+// each) + a FOUR-stage ring of weight items (320 rows x 64 B per (chunk, tap) item).  A DMA instruction covers 16 rows x 64 B;
+// the 16-byte piece of row h is XOR-swizzled on the source side with ((h >> 1) & 2): for 16 consecutive rows starting
+// ANYWHERE (the halo fragments start at an arbitrary pixel, shifted per tap) the four lane groups of a ds_read_b128 then
+// touch 16 distinct 16-byte bank slots.  Ping-pong at item granularity as in gemm_wide.hip:
+//   [ds_read 14 fragments | wait own DMAs of item i+1] barrier [issue halo piece (taps 0..3) + weight item i+3 | 40 MFMAs] barrier
+// with the two 4-wave halves one barrier out of phase.  Epilogue: wide_epilogue (bias, per-step bias, residual, out_scale).
+//
+// Reference op replaced: the ResnetBlock2D 3x3 convolutions and the up-/down-sampler convolutions of the UNet
+// (diffusers/src/diffusers/models/resnet.py:445-552), i.e. ATen convolution.
+#include <cstdlib>
+
+#include "common.h"
+#include "gemm_device.h"
+#include "gemm_wide_device.h"
+
+namespace tango {
+
+static constexpr int CW_HALO_MAX = 480;    // halo pixels per tile: 2 x 30 KiB halo + 80 KiB weight ring + 10 KiB source offsets = 150 KiB
+static constexpr int CW_NA = 4;            // halo DMA pieces (16 rows) per wave per channel chunk: 8 waves x 4 x 16 rows >= 480
+
+template <typename T, bool RES>
+__global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, const unsigned char* zero_page, const int SR, const int nseg,
+                                                           const int abytes) {
+  constexpr int BM = 256, BN = 320, CB = 64, NST = 4;
+  constexpr int BK = CB / (int)sizeof(T);       // 32 channels per chunk
+  constexpr int WST = BN * CB;                  // bytes per weight stage
+  constexpr int WRG = BN / 16;                  // 16-row DMA groups per weight item: 20
+  constexpr int WRGW = (WRG + 7) / 8;           // per wave: 3 (waves 0-3) or 2
+  constexpr int TM = 4, TN = 10;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // [halo 0 | halo 1 | W stage 0..3]
+  unsigned char* const As = dsm;
+  unsigned char* const Ws = dsm + 2 * abytes;
+
+  const int NT = p.N / BN;
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (bid / NT) * BM, n0 = (bid % NT) * BN;
+  const unsigned char* Ab = (const unsigned char*)p.A;
+  const unsigned char* Wb = (const unsigned char*)p.W;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int lrow = lane >> 2, slot = lane & 3;
+
+  // tile geometry: 256 consecutive pixels = SR image rows of one image (nseg == 1) or nseg whole images
+  const int H = p.H, Wd = p.Wd, hw = H * Wd;
+  const int HW2 = Wd + 2, SEG = (SR + 2) * HW2;
+  const int HALO = nseg * SEG, HALO_RG = (HALO + 15) >> 4;
+  const int b0 = m0 / hw;
+  const int y0 = nseg == 1 ? (m0 - b0 * hw) / Wd : 0;
+
+  // halo DMA sources: piece t of wave w covers halo rows (t*8 + w)*16 + lrow.  The 32-bit byte offsets of the (swizzled)
+  // 16-byte pieces live in LDS behind the weight ring (5 dwords per thread; ~0u = outside the image -> zero page): with 160
+  // accumulator + 56 fragment registers there is no room to keep them in VGPRs (hipcc spilled them and reloaded them with
+  // s_waitcnt vmcnt(0) in the middle of the DMA pipeline).
+  unsigned* const aoff_lds = (unsigned*)(Ws + NST * WST) + tid;   // [CW_NA halo pieces | weight group 0] x 512 threads
+#pragma unroll
+  for (int t = 0; t < CW_NA; ++t) {
+    unsigned off = ~0u;
+    const int h = ((t * 8 + wave) << 4) + lrow;
+    if (h < HALO) {
+      const int seg = h / SEG, rem = h - seg * SEG;
+      const int hy = rem / HW2, hx = rem - hy * HW2;
+      const int y = y0 + hy - 1, x = hx - 1;
+      const int pc = slot ^ ((h >> 1) & 2);
+      // fused nearest x2 upsampling (p.ups): the halo lives on the upsampled grid, pixel (y, x) reads source (y>>1, x>>1)
+      if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)Wd)
+        off = (unsigned)(((((int64_t)(b0 + seg) * p.Hin + (y >> p.ups)) * p.Win + (x >> p.ups)) * p.lda) * (int64_t)sizeof(T) + pc * 16);
+    }
+    aoff_lds[t * 512] = off;
+  }
+  // weight DMA sources: row group rg = wave + 8 i, row = rg*16 + lrow: 32-bit offset of group 0 from the tile's first weight
+  // row, groups 1, 2 are 128 rows further each (same swizzle: (128 >> 1) & 2 == 0)
+  const int wrow_d = wave * 16 + lrow;
+  aoff_lds[CW_NA * 512] = (unsigned)(((int64_t)wrow_d * p.Kp) * (int64_t)sizeof(T) + ((slot ^ ((wrow_d >> 1) & 2)) * 16));
+  const unsigned w_step = (unsigned)(128 * p.Kp * (int64_t)sizeof(T));
+  const unsigned char* const Wt = Wb + (int64_t)n0 * p.Kp * (int64_t)sizeof(T);
+  const int my_w = wave < WRG - 8 * (WRGW - 1) ? WRGW : WRGW - 1;      // wave-uniform
+
+  auto issue_a = [&](const int t, const int cc, const int buf) {
+    const int ag = t * 8 + wave;
+    if (ag < HALO_RG) {
+      const unsigned off = aoff_lds[t * 512];
+      const unsigned char* src = off != ~0u ? Ab + (int64_t)cc * CB + off : zero_page;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * abytes + ag * 1024), 16, 0, 0);
+    }
+  };
+  // (the item's k offset is wave-uniform and made opaque per call: otherwise hipcc hoists the 27 (tap, group) source addresses
+  //  out of the chunk loop as 64-bit VGPR pairs and spills them)
+  auto issue_w = [&](const int tap, const int cc, const int st) {
+    int koff = (tap * p.Cin + cc * BK) * (int)sizeof(T);
+    asm volatile("" : "+s"(koff));
+    const unsigned char* base = Wt + koff;
+    const unsigned w_off0 = aoff_lds[CW_NA * 512];
+#pragma unroll
+    for (int i = 0; i < WRGW; ++i) {
+      const int rg = wave + 8 * i;
+      if (rg < WRG) {
+        unsigned o = w_off0 + i * w_step;
+        asm volatile("" : "+v"(o));               // keeps the zero-extended 64-bit forms of the three offsets out of the loop-invariant set
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + o), (lptr_t)(Ws + st * WST + rg * 1024), 16, 0, 0);
+      }
+    }
+  };
+  // at most the youngest `items` weight items of this wave may stay in flight (halo pieces are older than the weight item
+  // issued behind them, so they are covered by the same wait)
+  auto wait_items = [&](const int items) {
+    if (items <= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+    if (my_w == WRGW) {
+      if (items == 1) wait_vmcnt_lit<WRGW>();
+      else wait_vmcnt_lit<2 * WRGW>();
+    } else {
+      if (items == 1) wait_vmcnt_lit<WRGW - 1>();
+      else wait_vmcnt_lit<2 * (WRGW - 1)>();
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing: halo row of this lane's pixel in row-block b = h0 + hd[b]; the host guarantees geometries in which
+  // 16-pixel blocks are whole image rows or aligned pieces of one (Wd | 16 or 16 | Wd, 16 | H*Wd), so hd[b] is wave-uniform
+  // (three SGPRs instead of eight VGPRs: there is no register to spare next to 160 accumulators + 56 fragment registers)
+  int h0 = 0, hd[TM];
+#pragma unroll
+  for (int b = 0; b < TM; ++b) {
+    const int pm = wm * 64 + b * 16 + (lane & 15);
+    const int seg = pm / hw, r = pm - seg * hw;      // nseg == 1: hw >= 256 > pm -> seg = 0
+    const int ly = r / Wd, x = r - ly * Wd;
+    const int hb_ = seg * SEG + ly * HW2 + x;
+    if (b == 0) h0 = hb_;
+    hd[b] = __builtin_amdgcn_readfirstlane(hb_ - h0);
+  }
+  const int kg = lane >> 4;
+  const int wrow0 = wn * (TN * 16) + (lane & 15);
+  const int wfoff = wrow0 * CB + ((kg ^ ((wrow0 >> 1) & 2)) << 4);     // + a*16*CB: (a*16 >> 1) & 2 == 0
+
+  const int NC = p.Cin / BK;
+  const int NI = NC * 9;                            // (chunk, tap) items
+
+  const int half = wave >> 2;                       // one workgroup per CU: waves w and w + 4 share a SIMD (tools/simd_probe.hip)
+  // prologue: halo of chunk 0, weight items 0..2; item 0 (and the halo) must have landed before the first read
+#pragma unroll
+  for (int t = 0; t < CW_NA; ++t) issue_a(t, 0, 0);
+  issue_w(0, 0, 0);
+  issue_w(1, 0, 1);
+  issue_w(2, 0, 2);
+  wait_items(2);
+  pp_barrier();
+  if (half) pp_barrier();                           // the stagger: half B starts one slot late
+  int st = 0, item = 0;
+  for (int cc = 0; cc < NC; ++cc) {
+    const unsigned char* Ah = As + (cc & 1) * abytes;
+    const bool more_c = cc + 1 < NC;
+#pragma unroll 1                                    // one loop body: unrolled, the nine bodies pushed the allocator over 256 VGPRs
+    for (int tap = 0; tap < 9; ++tap, ++item) {
+      const unsigned char* Wst = Ws + st * WST;
+      const int toff = (tap / 3) * HW2 + (tap % 3);
+      // ---- read part ----
+      u32x4 wf[TN], xf[TM];
+#pragma unroll
+      for (int a = 0; a < TN; ++a) wf[a] = *(const u32x4*)(Wst + wfoff + a * 16 * CB);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        int hs = hd[b] + toff;                       // wave-uniform part, opaque per tap: 36 hoisted lane addresses would not fit
+        asm volatile("" : "+s"(hs));
+        const int h = h0 + hs;
+        xf[b] = *(const u32x4*)(Ah + h * CB + ((kg ^ ((h >> 1) & 2)) << 4));
+      }
+      // item i+1 must have landed before the barrier that precedes anybody's read of it; item i+2 may stay in flight
+      if (item + 1 < NI) wait_items(item + 2 < NI ? 1 : 0);
+      pp_barrier();
+      // ---- multiply part ----
+      if (more_c && tap < CW_NA) issue_a(tap, cc + 1, (cc + 1) & 1);
+      {
+        const int t3 = tap + 3;
+        const int st3 = st == 0 ? 3 : st - 1;       // (st + 3) % 4: the stage of item i-1
+        if (t3 < 9) issue_w(t3, cc, st3);
+        else if (more_c) issue_w(t3 - 9, cc + 1, st3);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) Mma<T>::run(acc[a][b], wf[a], xf[b]);
+      __builtin_amdgcn_s_setprio(0);
+      pp_barrier();
+      st = st == NST - 1 ? 0 : st + 1;
+    }
+  }
+  if (!half) pp_barrier();
+  __syncthreads();   // every wave is past its last fragment read: the halo / weight LDS becomes the staging area
+  const float mean[TM] = {0.f, 0.f, 0.f, 0.f}, rstd[TM] = {1.f, 1.f, 1.f, 1.f};
+  wide_epilogue<T, false, RES, false>(p, acc, mean, rstd, m0 + wm * 64, n0 + wn * (TN * 16), lane, dsm + wave * (WIDE_STAGE_BYTES + 1280));
+}
+
+struct WideHaloGeom {
+  int SR, nseg, halo;
+};
+
+static bool wide_halo_geom(const GemmParams& p, WideHaloGeom& g) {
+  const int hw = p.H * p.Wd;
+  if (p.Wd <= 0 || 256 % p.Wd != 0) return false;
+  if (hw >= 256) {
+    if (hw % 256 != 0) return false;
+    g.SR = 256 / p.Wd; g.nseg = 1;
+  } else {
+    if (256 % hw != 0) return false;
+    g.SR = p.H; g.nseg = 256 / hw;
+  }
+  g.halo = g.nseg * (g.SR + 2) * (p.Wd + 2);
+  if (!((16 % p.Wd == 0 || p.Wd % 16 == 0) && hw % 16 == 0)) return false;   // wave-uniform row-block offsets (see the kernel)
+  return g.halo <= CW_HALO_MAX;
+}
+
+bool conv_wide_ok(int dtype, const GemmParams& p) {
+  static const bool off = getenv("TANGO_NO_WIDE_CONV") != nullptr;      // experiment switch
+  if (off || dtype == DT_F32) return false;
+  if (p.mode != GATHER_2D || p.stride != 1 || p.ups < 0 || p.ups > 1 || (p.Hin << p.ups) != p.H || (p.Win << p.ups) != p.Wd) return false;
+  if (p.batch != 1 || p.splitk > 1 || p.a_act != ACT_NONE || p.e_act != ACT_NONE || p.epi != EPI_NONE || p.bias_rows || p.out_f32) return false;
+  if ((p.Cin * 2) % 64 != 0 || p.K != 9 * p.Cin || p.M % 256 != 0 || p.N % 320 != 0) return false;
+  if (p.ldo % 8 != 0 || ((uintptr_t)p.out & 15) || (p.R && (p.ldr % 8 != 0 || ((uintptr_t)p.R & 15)))) return false;
+  if ((p.lda * 2) % 16 != 0 || (p.Kp * 2) % 16 != 0 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
+  if (((uintptr_t)p.bias & 15) || ((uintptr_t)p.bias2 & 15) || (p.bias2 && p.bias2_stride % 4 != 0)) return false;
+  // 32-bit source offsets in the kernel: activation tensor and one tile's 320 weight rows below 4 GiB
+  if ((int64_t)(p.M >> (2 * p.ups)) * p.lda * 2 >= (int64_t)0xFFFF0000 || (int64_t)320 * p.Kp * 2 >= (int64_t)0xFFFF0000) return false;
+  WideHaloGeom g;
+  if (!wide_halo_geom(p, g)) return false;
+  static const bool force = getenv("TANGO_FORCE_DMA_GEMM") != nullptr;  // tests: exercise this kernel on small shapes
+  const long tiles = (long)(p.M / 256) * (p.N / 320);
+  return force || tiles >= 224;
+}
+
+template <typename T, bool RES>
+static int launch_conv_wide_cfg(const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {
+  WideHaloGeom g;
+  if (!wide_halo_geom(p, g)) TANGO_FAIL("conv_wide: unsupported geometry");
+  const int abytes = ((g.halo + 15) / 16) * 1024;
+  int lds = 2 * abytes + 4 * 320 * 64 + (CW_NA + 1) * 512 * 4;
+  const int epi_lds = 8 * (WIDE_STAGE_BYTES + 1280);
+  if (lds < epi_lds) lds = epi_lds;
+  auto kfn = conv3x3_wide_kernel<T, RES>;
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_lds = lds;
+  }
+  const int tiles = (p.M / 256) * (p.N / 320);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(512), lds, s, p, zero_page, g.SR, g.nseg, abytes);
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_conv_wide(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {
+  if (!zero_page) TANGO_FAIL("conv_wide: gemm_init() was not called (zero page for the LDS-DMA gather)");
+  switch (dtype) {
+    case DT_F16: return p.R ? launch_conv_wide_cfg<f16, true>(p, zero_page, s) : launch_conv_wide_cfg<f16, false>(p, zero_page, s);
+    case DT_BF16: return p.R ? launch_conv_wide_cfg<bf16, true>(p, zero_page, s) : launch_conv_wide_cfg<bf16, false>(p, zero_page, s);
+  }
+  TANGO_FAIL("conv_wide: 16-bit dtypes only");
+}
+
+}  // namespace tango

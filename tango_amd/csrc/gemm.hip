@@ -329,6 +329,7 @@ int launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
   if (p.ln_fold && (wide_ln || !linear_stream_ok(dtype, p)) && gemm_wide_ok(dtype, p)) return launch_gemm_wide(dtype, p, s);
   if (linear_stream_ok(dtype, p)) return launch_linear_stream(dtype, p, s);
   if (p.ln_fold) TANGO_FAIL("gemm: ln_fold is only implemented by the streaming linear kernel");
+  if (conv_wide_ok(dtype, p)) return launch_conv_wide(dtype, p, g_zero_page, s);
   if (conv_halo_ok(dtype, p)) return launch_conv_halo(dtype, p, g_zero_page, s);
   if (gemm_wide_ok(dtype, p)) return launch_gemm_wide(dtype, p, s);
   if (gemm_pers_ok(dtype, p)) return launch_gemm_pers(dtype, p, g_zero_page, s);

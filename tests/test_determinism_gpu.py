@@ -195,6 +195,24 @@ def test_conv3x3_repeat(lib, dtype, B, Cin, Cout, H, W, ups):
            tuple(ref.shape), ref, TOL[dtype], "conv3x3 %s" % dtype)
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ups", [(64, 64, 320, 64, 16, 0),      # W = 16: 16-row tiles, halo 18 x 18
+                                                (64, 96, 320, 128, 8, 0),      # W = 8, three 64-byte channel chunks
+                                                (256, 32, 320, 64, 4, 0),      # whole-image tiles (H * W = 256), one chunk
+                                                (32, 64, 640, 32, 8, 1),       # fused nearest x2 upsample, two column tiles
+                                                (28, 160, 640, 32, 32, 0)])    # W = 32: 8-row tiles
+def test_conv3x3_wide_repeat(lib, dtype, B, Cin, Cout, H, W, ups):
+    """halo-reuse conv on the 256 x 320 tile (conv_wide.hip): >= 224 tiles, every tile geometry the UNet uses"""
+    g = torch.Generator().manual_seed(Cin * Cout + H + W)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype).cuda()
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5, dtype).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    ref = F.conv2d(xin, w, b, padding=1).cpu()
+    repeat(lib, lambda out: lib.tango_op_conv2d(DT[dtype], p(x), p(w), p(b), p(out), B, Cin, H, W, Cout, 1, ups, None),
+           tuple(ref.shape), ref, TOL[dtype], "conv3x3 wide %s" % dtype)
+
+
 @pytest.mark.parametrize("dtype", ["fp16", "bf16", "fp32"])
 @pytest.mark.parametrize("B,heads,Sq,Skv,masked", [(2, 5, 4096, 4096, False), (4, 10, 1024, 1024, False), (4, 5, 4096, 64, True), (3, 2, 200, 7, True)])
 def test_attention_repeat(lib, dtype, B, heads, Sq, Skv, masked):
