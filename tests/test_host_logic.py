@@ -216,3 +216,10 @@ def test_build_pretrained_models_from_audioldm_ckpt():
     assert stft is None and isinstance(vae, FakeVAE)
     assert abs(seen["kw"]["scale_factor"] - 0.9227914214134216) < 1e-7 and seen["kw"]["ddconfig"]["ch_mult"] == [1, 2, 4]
     assert sorted(seen["sd"]) == ["decoder.conv_in.weight", "vocoder.conv_pre.bias"]
+
+
+def test_swizzle64_conflict_free():
+    """the 64-byte-row LDS swizzles of gemm_wide.hip / conv_wide.hip are conflict-free for ds_read_b128's lane groups
+    (tools/check_swizzle64.py asserts it exhaustively)"""
+    import runpy
+    runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_swizzle64.py"))
