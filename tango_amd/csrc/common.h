@@ -189,6 +189,9 @@ bool gemm_wide_ok(int dtype, const GemmParams& p);   // 256 x 320 ping-pong LDS-
 int launch_gemm_wide(int dtype, const GemmParams& p, hipStream_t s);
 bool conv_wide_ok(int dtype, const GemmParams& p);   // 3x3 halo-reuse conv on the 256 x 320 tile (conv_wide.hip)
 int launch_conv_wide(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s);
+int conv_wide_pick_splitk(int dtype, const GemmParams& p);
+int gemm_wide_pick_splitk(int dtype, const GemmParams& p);
+int launch_splitk_reduce(int dtype, const GemmParams& p, hipStream_t s);   // gemm.hip: sums ws [splits][M][N] and applies the epilogue
 bool gemm_dma_ok(int dtype, const GemmParams& p);
 int launch_gemm_dma(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s);
 int gemm_init();   // process-wide one-time setup (zero page); call before any launch and outside stream capture

@@ -27,7 +27,7 @@ namespace tango {
 static constexpr int CW_HALO_MAX = 480;    // halo pixels per tile: 2 x 30 KiB halo + 80 KiB weight ring + 10 KiB source offsets = 150 KiB
 static constexpr int CW_NA = 4;            // halo DMA pieces (16 rows) per wave per channel chunk: 8 waves x 4 x 16 rows >= 480
 
-template <typename T, bool RES>
+template <typename T, bool RES, bool SK>
 __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, const unsigned char* zero_page, const int SR, const int nseg,
                                                            const int abytes) {
   constexpr int BM = 256, BN = 320, CB = 64, NST = 4;
@@ -150,23 +150,29 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
   const int wrow0 = wn * (TN * 16) + (lane & 15);
   const int wfoff = wrow0 * CB + ((kg ^ ((wrow0 >> 1) & 2)) << 4);     // + a*16*CB: (a*16 >> 1) & 2 == 0
 
-  const int NC = p.Cin / BK;
-  const int NI = NC * 9;                            // (chunk, tap) items
+  // split-K: blockIdx.y takes a contiguous range of channel chunks (all nine taps each); partial tiles go to the workspace
+  int cc0 = 0, cc1 = p.Cin / BK;
+  if (SK) {
+    const int per = (cc1 + (int)gridDim.y - 1) / (int)gridDim.y;
+    cc0 = (int)blockIdx.y * per;
+    cc1 = cc1 < cc0 + per ? cc1 : cc0 + per;
+  }
+  const int NI = (cc1 - cc0) * 9;                   // (chunk, tap) items of this workgroup
 
   const int half = wave >> 2;                       // one workgroup per CU: waves w and w + 4 share a SIMD (tools/simd_probe.hip)
   // prologue: halo of chunk 0, weight items 0..2; item 0 (and the halo) must have landed before the first read
 #pragma unroll
-  for (int t = 0; t < CW_NA; ++t) issue_a(t, 0, 0);
-  issue_w(0, 0, 0);
-  issue_w(1, 0, 1);
-  issue_w(2, 0, 2);
+  for (int t = 0; t < CW_NA; ++t) issue_a(t, cc0, cc0 & 1);
+  issue_w(0, cc0, 0);
+  issue_w(1, cc0, 1);
+  issue_w(2, cc0, 2);
   wait_items(2);
   pp_barrier();
   if (half) pp_barrier();                           // the stagger: half B starts one slot late
   int st = 0, item = 0;
-  for (int cc = 0; cc < NC; ++cc) {
+  for (int cc = cc0; cc < cc1; ++cc) {
     const unsigned char* Ah = As + (cc & 1) * abytes;
-    const bool more_c = cc + 1 < NC;
+    const bool more_c = cc + 1 < cc1;
 #pragma unroll 1                                    // one loop body: unrolled, the nine bodies pushed the allocator over 256 VGPRs
     for (int tap = 0; tap < 9; ++tap, ++item) {
       const unsigned char* Wst = Ws + st * WST;
@@ -205,8 +211,13 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
   }
   if (!half) pp_barrier();
   __syncthreads();   // every wave is past its last fragment read: the halo / weight LDS becomes the staging area
+  unsigned char* const slice = dsm + wave * (WIDE_STAGE_BYTES + 1280);
+  if (SK) {
+    wide_epilogue_raw(p, acc, (int)blockIdx.y, m0 + wm * 64, n0 + wn * (TN * 16), lane, slice);
+    return;
+  }
   const float mean[TM] = {0.f, 0.f, 0.f, 0.f}, rstd[TM] = {1.f, 1.f, 1.f, 1.f};
-  wide_epilogue<T, false, RES, false>(p, acc, mean, rstd, m0 + wm * 64, n0 + wn * (TN * 16), lane, dsm + wave * (WIDE_STAGE_BYTES + 1280));
+  wide_epilogue<T, false, RES, false>(p, acc, mean, rstd, m0 + wm * 64, n0 + wn * (TN * 16), lane, slice);
 }
 
 struct WideHaloGeom {
@@ -232,7 +243,8 @@ bool conv_wide_ok(int dtype, const GemmParams& p) {
   static const bool off = getenv("TANGO_NO_WIDE_CONV") != nullptr;      // experiment switch
   if (off || dtype == DT_F32) return false;
   if (p.mode != GATHER_2D || p.stride != 1 || p.ups < 0 || p.ups > 1 || (p.Hin << p.ups) != p.H || (p.Win << p.ups) != p.Wd) return false;
-  if (p.batch != 1 || p.splitk > 1 || p.a_act != ACT_NONE || p.e_act != ACT_NONE || p.epi != EPI_NONE || p.bias_rows || p.out_f32) return false;
+  if (p.batch != 1 || p.a_act != ACT_NONE || p.epi != EPI_NONE || p.bias_rows) return false;
+  if (p.splitk > 1 ? (!p.ws || p.splitk > p.Cin / 32 || p.N % 4 != 0) : (p.e_act != ACT_NONE || p.out_f32)) return false;
   if ((p.Cin * 2) % 64 != 0 || p.K != 9 * p.Cin || p.M % 256 != 0 || p.N % 320 != 0) return false;
   if (p.ldo % 8 != 0 || ((uintptr_t)p.out & 15) || (p.R && (p.ldr % 8 != 0 || ((uintptr_t)p.R & 15)))) return false;
   if ((p.lda * 2) % 16 != 0 || (p.Kp * 2) % 16 != 0 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
@@ -242,11 +254,30 @@ bool conv_wide_ok(int dtype, const GemmParams& p) {
   WideHaloGeom g;
   if (!wide_halo_geom(p, g)) return false;
   static const bool force = getenv("TANGO_FORCE_DMA_GEMM") != nullptr;  // tests: exercise this kernel on small shapes
-  const long tiles = (long)(p.M / 256) * (p.N / 320);
+  const long tiles = (long)(p.M / 256) * (p.N / 320) * (p.splitk > 1 ? p.splitk : 1);
   return force || tiles >= 224;
 }
 
-template <typename T, bool RES>
+// split-K factor the wide conv wants for a problem whose 256 x 320 tiling does not fill the chip (0: not a wide-conv problem)
+int conv_wide_pick_splitk(int dtype, const GemmParams& p) {
+  GemmParams q = p;
+  q.splitk = 1;
+  static const bool force = getenv("TANGO_FORCE_DMA_GEMM") != nullptr;
+  if (force || p.mode != GATHER_2D || dtype == DT_F32 || p.M % 256 != 0 || p.N % 320 != 0 || p.Cin % 32 != 0) return 0;
+  const long tiles = (long)(p.M / 256) * (p.N / 320);
+  // measured (B = 8 / 16 UNet steps, profiles/r2_unet_ops_small_batch_splitk.txt): 64 tiles x 4 splits beat the 4-wave tiles'
+  // split-K by 21-27 %; 128 tiles x 2 splits LOSE to the unsplit 256 x 160 halo kernel by 14-20 %
+  if (tiles > 96 || tiles < 16) return 0;
+  int s = (int)((256 + tiles / 2) / tiles);          // one workgroup per CU
+  const int nc = p.Cin / 32;
+  if (s > nc / 4) s = nc / 4;                        // >= 4 channel chunks (36 items) per split
+  if (s < 2) return 0;
+  float dummy_ws = 0.f;
+  q.splitk = s; q.ws = &dummy_ws;
+  return conv_wide_ok(dtype, q) ? s : 0;
+}
+
+template <typename T, bool RES, bool SK = false>
 static int launch_conv_wide_cfg(const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {
   WideHaloGeom g;
   if (!wide_halo_geom(p, g)) TANGO_FAIL("conv_wide: unsupported geometry");
@@ -254,23 +285,28 @@ static int launch_conv_wide_cfg(const GemmParams& p, const unsigned char* zero_p
   int lds = 2 * abytes + 4 * 320 * 64 + (CW_NA + 1) * 512 * 4;
   const int epi_lds = 8 * (WIDE_STAGE_BYTES + 1280);
   if (lds < epi_lds) lds = epi_lds;
-  auto kfn = conv3x3_wide_kernel<T, RES>;
+  auto kfn = conv3x3_wide_kernel<T, RES, SK>;
   static int attr_lds = 0;
   if (lds > attr_lds) {
     TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_lds = lds;
   }
   const int tiles = (p.M / 256) * (p.N / 320);
-  hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(512), lds, s, p, zero_page, g.SR, g.nseg, abytes);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)tiles, (unsigned)(p.splitk > 1 ? p.splitk : 1)), dim3(512), lds, s, p, zero_page, g.SR, g.nseg, abytes);
   TANGO_HIP(hipGetLastError());
+  if (p.splitk > 1) TANGO_TRY(launch_splitk_reduce(TypeTag<T>::dt, p, s));
   return 0;
 }
 
 int launch_conv_wide(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {
   if (!zero_page) TANGO_FAIL("conv_wide: gemm_init() was not called (zero page for the LDS-DMA gather)");
   switch (dtype) {
-    case DT_F16: return p.R ? launch_conv_wide_cfg<f16, true>(p, zero_page, s) : launch_conv_wide_cfg<f16, false>(p, zero_page, s);
-    case DT_BF16: return p.R ? launch_conv_wide_cfg<bf16, true>(p, zero_page, s) : launch_conv_wide_cfg<bf16, false>(p, zero_page, s);
+    case DT_F16:
+      if (p.splitk > 1) return launch_conv_wide_cfg<f16, false, true>(p, zero_page, s);
+      return p.R ? launch_conv_wide_cfg<f16, true>(p, zero_page, s) : launch_conv_wide_cfg<f16, false>(p, zero_page, s);
+    case DT_BF16:
+      if (p.splitk > 1) return launch_conv_wide_cfg<bf16, false, true>(p, zero_page, s);
+      return p.R ? launch_conv_wide_cfg<bf16, true>(p, zero_page, s) : launch_conv_wide_cfg<bf16, false>(p, zero_page, s);
   }
   TANGO_FAIL("conv_wide: 16-bit dtypes only");
 }

@@ -237,6 +237,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
   }
 }
 
+int launch_splitk_reduce(int dtype, const GemmParams& p, hipStream_t s) {
+  const int64_t work = (int64_t)p.M * (p.N / 4);
+  const dim3 grid((unsigned)((work + 255) / 256));
+  switch (dtype) {
+    case DT_F32: hipLaunchKernelGGL((splitk_reduce_kernel<float>), grid, dim3(256), 0, s, p); break;
+    case DT_F16: hipLaunchKernelGGL((splitk_reduce_kernel<f16>), grid, dim3(256), 0, s, p); break;
+    case DT_BF16: hipLaunchKernelGGL((splitk_reduce_kernel<bf16>), grid, dim3(256), 0, s, p); break;
+    default: TANGO_FAIL("splitk_reduce: bad dtype");
+  }
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename T, int BM, int BN, int BKB, int WM, int WN, int MODE>
 static int launch_cfg(const GemmParams& p, hipStream_t s) {
   const int MT = (p.M + BM - 1) / BM, NT = (p.N + BN - 1) / BN;
@@ -307,6 +320,15 @@ int gemm_pick_splitk(int dtype, const GemmParams& p) {
   if (p.mode == GATHER_1D && !(p.taps == 1 && p.rows_pb == p.M && p.in_mul == 1 && p.in_off == 0 && p.out_mul == 1 && p.out_off == 0))
     return 1;
   if (linear_stream_ok(dtype, p)) return 1;
+  static const bool wide_sk = getenv("TANGO_NO_WIDE_SPLITK") == nullptr;          // experiment switch
+  if (wide_sk) {
+    int sw = conv_wide_pick_splitk(dtype, p);          // e.g. 64 tiles of 256 x 320 -> 4 splits = one workgroup per CU
+    // linears: measured at M = 4096 (64 tiles x 4 splits) the wide kernel is no faster than the 4-wave tiles' split-K
+    // (0.250 vs 0.212 ms for N = K = 1280 x5): opt-in
+    static const bool wide_sk_lin = getenv("TANGO_WIDE_SPLITK_LINEAR") != nullptr;
+    if (sw <= 1 && wide_sk_lin) sw = gemm_wide_pick_splitk(dtype, p);
+    if (sw > 1) return sw;
+  }
   const int esz = dtype == DT_F32 ? 4 : 2;
   const int bk = ((p.Cin * esz) % 128 == 0) ? 128 / esz : 64 / esz;
   const int nk = p.K / bk;
@@ -325,6 +347,7 @@ int launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
   // the 256 x 320 kernel also beats the streaming kernel on its plain (no folded LayerNorm) shapes once a row is >= 1280 bytes
   // (measured, same box: M=65536 N=640 K=640 x20 2.38 -> 1.87 ms; K=320 rows: no difference, stay on the streaming kernel)
   if (!p.ln_fold && (p.K >= 640 || p.epi == EPI_VT) && gemm_wide_ok(dtype, p)) return launch_gemm_wide(dtype, p, s);
+  if (p.splitk > 1 && p.mode == GATHER_1D && gemm_wide_ok(dtype, p)) return launch_gemm_wide(dtype, p, s);
   static const bool wide_ln = !(getenv("TANGO_WIDE_LN") && getenv("TANGO_WIDE_LN")[0] == '0');   // experiment switch
   if (p.ln_fold && (wide_ln || !linear_stream_ok(dtype, p)) && gemm_wide_ok(dtype, p)) return launch_gemm_wide(dtype, p, s);
   if (linear_stream_ok(dtype, p)) return launch_linear_stream(dtype, p, s);

@@ -51,7 +51,7 @@ template <typename T> __device__ __forceinline__ void wide_frag_stats(const u32x
   }
 }
 
-template <typename T, bool GEGLU, bool RES, bool LN, bool VT>
+template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool SK>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, const int pp_mode, unsigned long long* __restrict__ trace) {
   constexpr int BM = 256, BN = 320, CB = 64, NST = 4;
   constexpr int ROWS = BM + BN, STAGE = ROWS * CB;
@@ -86,13 +86,20 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
     r_base[i] = i < 2 ? ((int64_t)(m0 + row) * p.lda) * (int64_t)sizeof(T) + pc * 16
                       : ((int64_t)(n0 + row - BM) * p.Kp) * (int64_t)sizeof(T) + pc * 16;
   }
+  // split-K (plain epilogue only): blockIdx.y takes a contiguous range of k-chunks, partial tiles go to the workspace
+  int kc0 = 0, nk = (p.K * (int)sizeof(T)) / CB;
+  if (SK) {
+    const int per = (nk + (int)gridDim.y - 1) / (int)gridDim.y;
+    kc0 = (int)blockIdx.y * per;
+    nk = (nk < kc0 + per ? nk : kc0 + per) - kc0;
+  }
   const int my_count = wave < RG - 8 * (RGW - 1) ? RGW : RGW - 1;      // wave-uniform
   auto issue_chunk = [&](const int kc, const int st) {
 #pragma unroll
     for (int i = 0; i < RGW; ++i) {
       const int rg = wave + 8 * i;
       if (rg < RG) {
-        const unsigned char* src = (i < 2 ? Ab : Wb) + r_base[i] + (int64_t)kc * CB;
+        const unsigned char* src = (i < 2 ? Ab : Wb) + r_base[i] + (int64_t)(kc0 + kc) * CB;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dsm + st * STAGE + rg * 1024), 16, 0, 0);
       }
     }
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
     for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   float ssum[TM] = {0.f, 0.f, 0.f, 0.f}, ssq[TM] = {0.f, 0.f, 0.f, 0.f};
-  const int nk = (p.K * (int)sizeof(T)) / CB;
+
   const int l15 = lane & 15, g = lane >> 4;
   const int foff = l15 * CB + ((g ^ ((4 - (l15 >> 2)) & 3)) * 16);
   const int xrow = (wm * TM * 16) * CB + foff;
@@ -174,6 +181,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
     }
   }
   unsigned char* const slice = dsm + wave * (WIDE_STAGE_BYTES + 1280);
+  if (SK) {
+    wide_epilogue_raw(p, acc, (int)blockIdx.y, m0 + wm * TM * 16, n0 + wn * TN * 16, lane, slice);
+    return;
+  }
   if (VT && n0 >= p.vt_n0) wide_epilogue_vt<T, LN>(p, acc, mean, rstd, m0 + wm * TM * 16, n0 + wn * TN * 16, lane, slice);
   else wide_epilogue<T, GEGLU, RES, LN>(p, acc, mean, rstd, m0 + wm * TM * 16, n0 + wn * TN * 16, lane, slice);
   if (trace && tid == 0) {
@@ -191,7 +202,8 @@ bool gemm_wide_ok(int dtype, const GemmParams& p) {
   if (off || dtype == DT_F32) return false;
   const bool linear = p.mode == GATHER_1D && p.taps == 1 && p.rows_pb == p.M && p.in_mul == 1 && p.in_off == 0 && p.out_mul == 1 &&
                       p.out_off == 0 && p.Lin >= p.M;
-  if (!linear || p.batch != 1 || p.splitk > 1 || p.a_act != ACT_NONE || p.bias_rows || p.out_f32) return false;
+  if (!linear || p.batch != 1 || p.a_act != ACT_NONE || p.bias_rows) return false;
+  if (p.splitk > 1 ? (!p.ws || p.epi != EPI_NONE || p.ln_fold || p.N % 4 != 0 || p.splitk * 4 > p.K / 32) : p.out_f32) return false;
   if (p.ln_fold && (!p.wsum || ((uintptr_t)p.wsum & 15) || p.alpha != 1.f)) return false;
   if (p.epi != EPI_NONE && p.epi != EPI_GEGLU && p.epi != EPI_VT) return false;
   if (p.epi == EPI_VT && (p.R || p.bias2 || p.vt_n0 % 320 != 0 || p.vt_S % 256 != 0 || p.vt_ld % 8 != 0 || ((uintptr_t)p.vt & 15))) return false;
@@ -206,26 +218,43 @@ bool gemm_wide_ok(int dtype, const GemmParams& p) {
   if ((p.lda * 2) % 16 != 0 || (p.Kp * 2) % 16 != 0 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
   if (((uintptr_t)p.bias & 15) || ((uintptr_t)p.bias2 & 15) || (p.bias2 && p.bias2_stride % 4 != 0)) return false;
   static const bool force = getenv("TANGO_FORCE_DMA_GEMM") != nullptr;   // tests: exercise this kernel on small shapes
-  const long tiles = (long)(p.M / 256) * (p.N / 320);
+  const long tiles = (long)(p.M / 256) * (p.N / 320) * (p.splitk > 1 ? p.splitk : 1);
   return force || tiles >= 224;
 }
 
-template <typename T, bool GEGLU, bool RES, bool LN, bool VT = false>
+// split-K factor the wide GEMM wants for a linear whose 256 x 320 tiling does not fill the chip (0: not a wide-GEMM problem)
+int gemm_wide_pick_splitk(int dtype, const GemmParams& p) {
+  static const bool force = getenv("TANGO_FORCE_DMA_GEMM") != nullptr;
+  if (force || dtype == DT_F32 || p.mode != GATHER_1D || p.M % 256 != 0 || p.N % 320 != 0 || p.K % 32 != 0 || p.K < 640) return 0;
+  const long tiles = (long)(p.M / 256) * (p.N / 320);
+  if (tiles >= 224 || tiles < 16) return 0;
+  int s = (int)((256 + tiles / 2) / tiles);          // one workgroup per CU
+  if (s > p.K / 32 / 8) s = p.K / 32 / 8;            // >= 8 k-chunks per split
+  if (s < 2) return 0;
+  GemmParams q = p;
+  float dummy_ws = 0.f;
+  q.splitk = s; q.ws = &dummy_ws;
+  return gemm_wide_ok(dtype, q) ? s : 0;
+}
+
+template <typename T, bool GEGLU, bool RES, bool LN, bool VT = false, bool SK = false>
 static int launch_wide_cfg(const GemmParams& p, hipStream_t s) {
   constexpr int LDS = 4 * (256 + 320) * 64;
-  auto kfn = gemm_wide_kernel<T, GEGLU, RES, LN, VT>;
+  auto kfn = gemm_wide_kernel<T, GEGLU, RES, LN, VT, SK>;
   static bool attr_set = false;
   if (!attr_set) {
     TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   static const int pp_mode = getenv("TANGO_PP_HALF") ? atoi(getenv("TANGO_PP_HALF")) : 0;   // 0: waves w, w + 4 (one workgroup per CU: they share a SIMD, tools/simd_probe); 1: read HW_ID (+1 us per tile)
-  static const bool tracing = getenv("TANGO_WIDE_TRACE") != nullptr;                        // diagnostic: per-workgroup phase times
+  static const bool tracing_env = getenv("TANGO_WIDE_TRACE") != nullptr;                    // diagnostic: per-workgroup phase times
+  const bool tracing = tracing_env && p.splitk <= 1;
   const unsigned grid = (unsigned)((p.M / 256) * (p.N / 320));
   unsigned long long* trace = nullptr;
   if (tracing) TANGO_HIP(hipMalloc((void**)&trace, (size_t)grid * 40));
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS, s, p, pp_mode, trace);
+  hipLaunchKernelGGL(kfn, dim3(grid, (unsigned)(p.splitk > 1 ? p.splitk : 1)), dim3(512), LDS, s, p, pp_mode, trace);
   TANGO_HIP(hipGetLastError());
+  if (p.splitk > 1) TANGO_TRY(launch_splitk_reduce(TypeTag<T>::dt, p, s));
   if (tracing) {
     std::vector<unsigned long long> h((size_t)grid * 5);
     TANGO_HIP(hipStreamSynchronize(s));
@@ -248,6 +277,7 @@ static int launch_wide_cfg(const GemmParams& p, hipStream_t s) {
 
 template <typename T>
 static int launch_wide_t(const GemmParams& p, hipStream_t s) {
+  if (p.splitk > 1) return launch_wide_cfg<T, false, false, false, false, true>(p, s);
   if (p.epi == EPI_VT) return p.ln_fold ? launch_wide_cfg<T, false, false, true, true>(p, s) : launch_wide_cfg<T, false, false, false, true>(p, s);
   if (p.ln_fold) {
     if (p.epi == EPI_GEGLU) return p.R ? launch_wide_cfg<T, true, true, true>(p, s) : launch_wide_cfg<T, true, false, true>(p, s);

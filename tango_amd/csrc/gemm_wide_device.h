@@ -165,4 +165,27 @@ __device__ __forceinline__ void wide_epilogue_vt(const GemmParams& p, f32x4 (&ac
   }
 }
 
+
+// Split-K partial tile: the wave's 64 x 160 fp32 accumulators, unmodified, into the workspace slice of this split
+// (ws [splits][M][N]; splitk_reduce_kernel sums the splits in order and applies the epilogue).  16 rows per pass through the
+// staging slice, 16-byte pieces: 640 per pass = ten full wave iterations.
+__device__ __forceinline__ void wide_epilogue_raw(const GemmParams& p, f32x4 (&acc)[10][4], const int split, const int m_base, const int n_base,
+                                                  const int lane, unsigned char* stage) {
+  constexpr int PITCH = 160 * 4 + 16;
+  const int l15 = lane & 15, g4 = (lane >> 4) * 4;
+  float* const wsb = p.ws + ((int64_t)split * p.M + m_base) * p.N + n_base;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+#pragma unroll
+    for (int a = 0; a < 10; ++a) *(f32x4*)(stage + l15 * PITCH + (a * 16 + g4) * 4) = acc[a][b];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 10; ++it) {
+      const int idx = lane + it * 64, row = idx / 40, pc = idx - row * 40;
+      *(f32x4*)(wsb + (int64_t)(b * 16 + row) * p.N + pc * 4) = *(const f32x4*)(stage + row * PITCH + pc * 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace tango

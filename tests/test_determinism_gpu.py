@@ -88,10 +88,12 @@ def test_linear_repeat(lib, dtype, M, N, K, res):
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
-@pytest.mark.parametrize("M,N,K,res", [(57344, 320, 160, 1), (65536, 640, 2560, 0), (16384, 1280, 1280, 1), (57344, 320, 128, 0)])
+@pytest.mark.parametrize("M,N,K,res", [(57344, 320, 160, 1), (65536, 640, 2560, 0), (16384, 1280, 1280, 1), (57344, 320, 128, 0),
+                                       (4096, 1280, 1280, 1), (8192, 640, 2560, 0)])     # split-K x4 / x4 (64 tiles of 256 x 320)
 def test_wide_gemm_repeat(lib, dtype, M, N, K, res):
     """256 x 320 ping-pong LDS-DMA GEMM (gemm_wide.hip): >= 224 tiles, k-chunk counts 4 (the minimum: prologue == whole K),
-    5, 40 and 80, with and without the residual epilogue, both 16-bit types"""
+    5, 40 and 80, with and without the residual epilogue, both 16-bit types; the last two cases run split-K (fp32 partial
+    tiles + the ordered reduce kernel)"""
     g = torch.Generator().manual_seed(M + N + K + res)
     x = q(torch.randn(M, K, generator=g), dtype).cuda()
     w = q(torch.randn(N, K, generator=g) / K ** 0.5, dtype).cuda()
@@ -200,7 +202,8 @@ def test_conv3x3_repeat(lib, dtype, B, Cin, Cout, H, W, ups):
                                                 (64, 96, 320, 128, 8, 0),      # W = 8, three 64-byte channel chunks
                                                 (256, 32, 320, 64, 4, 0),      # whole-image tiles (H * W = 256), one chunk
                                                 (32, 64, 640, 32, 8, 1),       # fused nearest x2 upsample, two column tiles
-                                                (28, 160, 640, 32, 32, 0)])    # W = 32: 8-row tiles
+                                                (28, 160, 640, 32, 32, 0),     # W = 32: 8-row tiles
+                                                (16, 512, 320, 64, 16, 0)])    # 64 tiles -> split-K x4 over the 16 channel chunks
 def test_conv3x3_wide_repeat(lib, dtype, B, Cin, Cout, H, W, ups):
     """halo-reuse conv on the 256 x 320 tile (conv_wide.hip): >= 224 tiles, every tile geometry the UNet uses"""
     g = torch.Generator().manual_seed(Cin * Cout + H + W)

@@ -1,14 +1,10 @@
 #!/bin/bash
-# gpurun call 22 of round 2: staggered starts on the wide GEMM (residual-epilogue shapes)
+# gpurun call 25 of round 2: smaller batches (B = 8, 16): wide-conv split-K on / off; B = 1 bench (config 2)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r2; mkdir -p $O
-export TANGO_WIDE_TRACE=1
-for st in 0 1600 3200 6400; do
-echo "stagger $st (10 ns)"
-{
-TANGO_WIDE_STAGGER=$st python tools/bench_ops.py linear 262144 320 640 3 res
-TANGO_WIDE_STAGGER=$st python tools/bench_ops.py linear 262144 320 1280 3 res
-TANGO_WIDE_STAGGER=$st python tools/bench_ops.py linear 65536 640 640 3 res
-TANGO_WIDE_STAGGER=$st python tools/bench_ops.py linear 65536 5120 640 3 nores geglu
-} 2>&1 | grep trace | awk 'NR%3==0' | sed 's/gemm_wide trace //'
-done | tee $O/wide_stagger.txt
+for b in 8 16; do
+timeout 200 python tools/profile_unet_ops.py --batch $b --out $O/unet_ops_b${b}_sk.txt > /dev/null 2>&1; head -1 $O/unet_ops_b${b}_sk.txt
+TANGO_NO_WIDE_SPLITK=1 timeout 200 python tools/profile_unet_ops.py --batch $b --out $O/unet_ops_b${b}_nosk.txt > /dev/null 2>&1; head -1 $O/unet_ops_b${b}_nosk.txt
+grep "^conv.*splitK" $O/unet_ops_b${b}_sk.txt | head -8; echo; grep "^conv" $O/unet_ops_b${b}_nosk.txt | head -12
+done
+timeout 600 python bench.py --batch 1 --denoise-steps 100 --no-cpu-baseline > $O/bench_v26_b1.json 2> $O/bench_v26_b1.err; cat $O/bench_v26_b1.json
