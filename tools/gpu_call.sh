@@ -1,10 +1,8 @@
 #!/bin/bash
-# gpurun call 25 of round 2: smaller batches (B = 8, 16): wide-conv split-K on / off; B = 1 bench (config 2)
+# gpurun call 27 of round 2: final numbers -- split-K test case, default bench (with cpu_baseline), bf16 and fp32 records
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r2; mkdir -p $O
-for b in 8 16; do
-timeout 200 python tools/profile_unet_ops.py --batch $b --out $O/unet_ops_b${b}_sk.txt > /dev/null 2>&1; head -1 $O/unet_ops_b${b}_sk.txt
-TANGO_NO_WIDE_SPLITK=1 timeout 200 python tools/profile_unet_ops.py --batch $b --out $O/unet_ops_b${b}_nosk.txt > /dev/null 2>&1; head -1 $O/unet_ops_b${b}_nosk.txt
-grep "^conv.*splitK" $O/unet_ops_b${b}_sk.txt | head -8; echo; grep "^conv" $O/unet_ops_b${b}_nosk.txt | head -12
-done
-timeout 600 python bench.py --batch 1 --denoise-steps 100 --no-cpu-baseline > $O/bench_v26_b1.json 2> $O/bench_v26_b1.err; cat $O/bench_v26_b1.json
+timeout 600 python -m pytest tests/test_determinism_gpu.py -m gpu -q -x -k "conv3x3_wide or wide_gemm_repeat" > $O/det_final.log 2>&1; echo "det rc=$?"; tail -2 $O/det_final.log
+timeout 900 python bench.py > $O/bench_v26.json 2> $O/bench_v26.err; cat $O/bench_v26.json
+timeout 600 python bench.py --dtype bf16 --denoise-steps 20 --no-cpu-baseline > $O/bench_v26_bf16.json 2> $O/bench_v26_bf16.err; cat $O/bench_v26_bf16.json | cut -c1-400
+timeout 600 python bench.py --dtype fp32 --denoise-steps 10 --no-cpu-baseline > $O/bench_v26_fp32.json 2> $O/bench_v26_fp32.err; cat $O/bench_v26_fp32.json | cut -c1-400
