@@ -65,6 +65,32 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     for (int e = 0; e < EPV; ++e) { s[j][e] = 0.f; ss[j][e] = 0.f; }
   const int r0 = chunk * RC, r1 = min(rows, r0 + RC);
   if (rl < RPB) {
+    if (VPR <= TPR) {
+      // one 16-byte piece per thread and row (every UNet width): four rows per iteration with all four loads issued before the
+      // first use -- the plain loop kept one load per thread in flight, ~30 KB per CU, short of what HBM latency x bandwidth
+      // needs; the accumulation order per thread (row order) is unchanged, so the statistics are bit-identical
+      if (tv < VPR) {
+        int r = r0 + rl;
+        for (; r + 3 * RPB < r1; r += 4 * RPB) {
+          u32x4 v4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v4[u] = *(const u32x4*)(x + ((int64_t)b * rows + r + u * RPB) * ldx + tv * EPV);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            float f[EPV];
+            unpack16<T>(v4[u], f);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) { s[0][e] += f[e]; ss[0][e] += f[e] * f[e]; }
+          }
+        }
+        for (; r < r1; r += RPB) {
+          float f[EPV];
+          unpack16<T>(*(const u32x4*)(x + ((int64_t)b * rows + r) * ldx + tv * EPV), f);
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) { s[0][e] += f[e]; ss[0][e] += f[e] * f[e]; }
+        }
+      }
+    } else {
     for (int r = r0 + rl; r < r1; r += RPB) {
       const T* row = x + ((int64_t)b * rows + r) * ldx;
 #pragma unroll
@@ -77,6 +103,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
           for (int e = 0; e < EPV; ++e) { s[j][e] += f[e]; ss[j][e] += f[e] * f[e]; }
         }
       }
+    }
     }
   }
   // reduce over rl through LDS (RPB*C <= 2048 when RPB > 1)
@@ -150,7 +177,28 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
   }
   const int r0 = chunk * RC, r1 = min(rows, r0 + RC);
-  for (int r = r0 + rl; r < r1; r += RPB) {
+  int rstart = r0 + rl;
+  if (VPR <= TPR && tv < VPR) {
+    // four rows per iteration, loads first (see gn_stats_kernel)
+    for (; rstart + 3 * RPB < r1; rstart += 4 * RPB) {
+      u32x4 v4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v4[u] = *(const u32x4*)(x + ((int64_t)b * rows + rstart + u * RPB) * ldx + tv * EPV);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[EPV];
+        unpack16<T>(v4[u], f);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          float t = f[e] * sc[0][e] + sh[0][e];
+          if (act == ACT_SILU) t = silu_f(t);
+          f[e] = t;
+        }
+        *(u32x4*)(y + ((int64_t)b * rows + rstart + u * RPB) * ldy + tv * EPV) = pack16<T>(f);
+      }
+    }
+  }
+  for (int r = rstart; r < r1; r += RPB) {
     const T* row = x + ((int64_t)b * rows + r) * ldx;
     T* orow = y + ((int64_t)b * rows + r) * ldy;
 #pragma unroll

@@ -1,8 +1,9 @@
 #!/bin/bash
-# gpurun call 27 of round 2: final numbers -- split-K test case, default bench (with cpu_baseline), bf16 and fp32 records
+# gpurun call 28 of round 2: GroupNorm with four rows in flight per thread -- tests, A/B against the previous library
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r2; mkdir -p $O
-timeout 600 python -m pytest tests/test_determinism_gpu.py -m gpu -q -x -k "conv3x3_wide or wide_gemm_repeat" > $O/det_final.log 2>&1; echo "det rc=$?"; tail -2 $O/det_final.log
-timeout 900 python bench.py > $O/bench_v26.json 2> $O/bench_v26.err; cat $O/bench_v26.json
-timeout 600 python bench.py --dtype bf16 --denoise-steps 20 --no-cpu-baseline > $O/bench_v26_bf16.json 2> $O/bench_v26_bf16.err; cat $O/bench_v26_bf16.json | cut -c1-400
-timeout 600 python bench.py --dtype fp32 --denoise-steps 10 --no-cpu-baseline > $O/bench_v26_fp32.json 2> $O/bench_v26_fp32.err; cat $O/bench_v26_fp32.json | cut -c1-400
+timeout 600 python -m pytest tests/test_ops_gpu.py -m gpu -q -x -k "groupnorm or norm" > $O/ops_gn.log 2>&1; echo "ops rc=$?"; tail -1 $O/ops_gn.log
+timeout 200 python tools/profile_unet_ops.py --out $O/unet_ops_gn4.txt > /dev/null 2>&1; head -1 $O/unet_ops_gn4.txt; grep "^groupnorm" $O/unet_ops_gn4.txt | head -8
+cp tango_amd/lib/libtango_hip.so /tmp/new.so; cp build/libtango_hip_gnbase.so tango_amd/lib/libtango_hip.so
+timeout 200 python tools/profile_unet_ops.py --out $O/unet_ops_gn1.txt > /dev/null 2>&1; head -1 $O/unet_ops_gn1.txt; grep "^groupnorm" $O/unet_ops_gn1.txt | head -8
+cp /tmp/new.so tango_amd/lib/libtango_hip.so
