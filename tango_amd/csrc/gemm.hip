@@ -346,7 +346,8 @@ int gemm_pick_splitk(int dtype, const GemmParams& p) {
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
   // the 256 x 320 kernel also beats the streaming kernel on its plain (no folded LayerNorm) shapes once a row is >= 1280 bytes
   // (measured, same box: M=65536 N=640 K=640 x20 2.38 -> 1.87 ms; K=320 rows: no difference, stay on the streaming kernel)
-  if (!p.ln_fold && (p.K >= 640 || p.epi == EPI_VT) && gemm_wide_ok(dtype, p)) return launch_gemm_wide(dtype, p, s);
+  // ... and short rows the streaming kernel has no instantiation for (conv_in as im2col + linear, K = 96: 207 -> ~50 us)
+  if (!p.ln_fold && (p.K >= 640 || p.epi == EPI_VT || !linear_stream_ok(dtype, p)) && gemm_wide_ok(dtype, p)) return launch_gemm_wide(dtype, p, s);
   if (p.splitk > 1 && p.mode == GATHER_1D && gemm_wide_ok(dtype, p)) return launch_gemm_wide(dtype, p, s);
   static const bool wide_ln = !(getenv("TANGO_WIDE_LN") && getenv("TANGO_WIDE_LN")[0] == '0');   // experiment switch
   if (p.ln_fold && (wide_ln || !linear_stream_ok(dtype, p)) && gemm_wide_ok(dtype, p)) return launch_gemm_wide(dtype, p, s);

@@ -15,7 +15,8 @@
 //     (lane (l15, g) reads row l15, piece g) conflict-free for ds_read_b128's four lane groups (MI355X_MICROARCH.md);
 //   * its own epilogue (wide_epilogue below: bias / residual / GEGLU, arithmetic bit-identical to the other GEMM kernels),
 //     16 or 32 rows per pass through the first stages of the operand ring.
-// Linear problems only (A [M][K] row-major, W [N][Kp]); M % 256 == 0, N % 320 == 0, K a multiple of 32 elements.
+// Linear problems only (A [M][K] row-major, W [N][Kp]); M % 256 == 0, N % 320 == 0, K a multiple of 32 elements (any number
+// of k-chunks >= 1: the prologue issues min(nk, 3) of them).
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -213,7 +214,7 @@ bool gemm_wide_ok(int dtype, const GemmParams& p) {
   static const bool vt320 = getenv("TANGO_WIDE_VT320") != nullptr;       // experiment switch: level-0 q | k | v^T projection too
   if (p.ln_fold && (p.epi == EPI_GEGLU || (p.K < 640 && !(vt320 && p.epi == EPI_VT)))) return false;
   if (p.e_act != ACT_NONE) return false;            // (an inlined activation switch per element bloated this kernel 10x: not supported here)
-  if (p.M % 256 != 0 || p.N % 320 != 0 || (p.K * 2) % 64 != 0 || p.K * 2 < 4 * 64) return false;
+  if (p.M % 256 != 0 || p.N % 320 != 0 || (p.K * 2) % 64 != 0) return false;
   if (p.ldo % 8 != 0 || ((uintptr_t)p.out & 15) || (p.R && (p.ldr % 8 != 0 || ((uintptr_t)p.R & 15)))) return false;
   if ((p.lda * 2) % 16 != 0 || (p.Kp * 2) % 16 != 0 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
   if (((uintptr_t)p.bias & 15) || ((uintptr_t)p.bias2 & 15) || (p.bias2 && p.bias2_stride % 4 != 0)) return false;

@@ -89,7 +89,8 @@ def test_linear_repeat(lib, dtype, M, N, K, res):
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
 @pytest.mark.parametrize("M,N,K,res", [(57344, 320, 160, 1), (65536, 640, 2560, 0), (16384, 1280, 1280, 1), (57344, 320, 128, 0),
-                                       (4096, 1280, 1280, 1), (8192, 640, 2560, 0)])     # split-K x4 / x4 (64 tiles of 256 x 320)
+                                       (4096, 1280, 1280, 1), (8192, 640, 2560, 0),      # split-K x4 / x4 (64 tiles of 256 x 320)
+                                       (57344, 320, 96, 1), (57344, 320, 64, 0), (57344, 320, 32, 1)])   # 3, 2, 1 k-chunks (< ring depth)
 def test_wide_gemm_repeat(lib, dtype, M, N, K, res):
     """256 x 320 ping-pong LDS-DMA GEMM (gemm_wide.hip): >= 224 tiles, k-chunk counts 4 (the minimum: prologue == whole K),
     5, 40 and 80, with and without the residual epilogue, both 16-bit types; the last two cases run split-K (fp32 partial
