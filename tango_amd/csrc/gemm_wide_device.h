@@ -7,14 +7,6 @@ namespace tango {
 
 constexpr int WIDE_STAGE_BYTES = 11520;   // per-wave staging: max(16 rows x 656 B, 32 rows x 336 B, 80 columns x 144 B); 1280 B of constants follow
 
-
-// Epilogue of one wave's 64 x 160 accumulator block, written for this tile (gemm_epilogue_staged16's generic residual /
-// predication logic compiled into ~3000 instructions of branches and took as long as the main loop: tools trace, 21-40 us per
-// tile).  GEGLU and RES are compile-time; the arithmetic and its order are those of gemm_epilogue_staged (acc * alpha + bias
-// [+ bias2] -> activation / gate -> fp32 staging -> + residual -> * out_scale -> one rounding), so results are bit-identical.
-// Passes of 16 rows (32 for GEGLU, whose output rows are half as wide) = 320 16-byte output pieces = exactly five wave
-// iterations, no partial one.  vmcnt retires in order and counts stores: the residual pieces of pass p+1 are requested BEFORE
-// the stores of pass p are issued, so waiting for them (vmcnt <= 2 * NIT) never waits for a store.
 // one accumulator quad -> pre-activation values: acc * alpha + bias, or the folded-LayerNorm form rstd * (acc - mean * wsum) + bias
 // (cst points at this quad's bias; its wsum sits 160 floats further)
 template <bool LN>
@@ -35,6 +27,13 @@ __device__ __forceinline__ f32x4 wide_col_value(const f32x4 av, const float mean
   return v;
 }
 
+// Epilogue of one wave's 64 x 160 accumulator block, written for this tile (gemm_epilogue_staged16's generic residual /
+// predication logic compiled into ~3000 instructions of branches and took as long as the main loop: tools trace, 21-40 us per
+// tile).  GEGLU and RES are compile-time; the arithmetic and its order are those of gemm_epilogue_staged (acc * alpha + bias
+// [+ bias2] -> activation / gate -> fp32 staging -> + residual -> * out_scale -> one rounding), so results are bit-identical.
+// Passes of 16 rows (32 for GEGLU, whose output rows are half as wide) = 320 16-byte output pieces = exactly five wave
+// iterations, no partial one.  vmcnt retires in order and counts stores: the residual pieces of pass p+1 are requested BEFORE
+// the stores of pass p are issued, so waiting for them (vmcnt <= 2 * NIT) never waits for a store.
 // LN: folded LayerNorm (see linear_stream.hip): y = rstd[m] * (acc - mean[m] * wsum[n]) + b'[n] with the row statistics the
 // main loop accumulated; acc - mean * wsum is the single-instruction form that linear_stream.hip's race notes call for.
 // The per-column constants (bias [+ bias2], wsum) sit in LDS behind the staging rows, not in 80 VGPRs.
