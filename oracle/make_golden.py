@@ -12,6 +12,7 @@ Every fixture is produced by importing the reference's own code (oracle/ref_impo
                        which no fork KAT covers)
   loop_ref.npz         models.py:224-249 loop (fork UNet + fork DDPMScheduler, global-RNG draws), 3 steps
   vae_voc_ref.npz      reference AutoencoderKL.decode_first_stage / decode_to_waveform outputs
+  vae_enc_ref.npz      reference AutoencoderKL.encode_first_stage / get_first_stage_encoding outputs
 Inputs are re-derived from seeds by the tests; only small slices / checksums / tiny state_dicts are stored.
 """
 import json
@@ -219,6 +220,25 @@ def vae_golden():
     print("vae/voc", checksum(mel), zlib.crc32(wav.tobytes()))
 
 
+def vae_enc_golden():
+    """reference AutoencoderKL.encode / get_first_stage_encoding (autoencoder.py:52-58,126-135) on a synthetic mel"""
+    vae = R.autoencoder_cls()(**R.vae_config()).eval()
+    shapes = W.vae_encoder_param_shapes(O.VAE_CONFIG)
+    vae.load_state_dict(W.synth_state_dict(shapes, 4321), strict=False)
+    g = torch.Generator().manual_seed(43)
+    mel = torch.randn(2, 1, 1024, 64, generator=g) * 2.0 - 4.0          # log-mel-like range
+    with torch.no_grad():
+        post = vae.encode_first_stage(mel)
+        torch.manual_seed(5)
+        z = vae.get_first_stage_encoding(post)                           # draws randn(mean.shape) from the global generator
+    mom = post.parameters
+    assert mom.shape == (2, 16, 256, 16) and z.shape == (2, 8, 256, 16)
+    np.savez_compressed(os.path.join(OUT, "vae_enc_ref.npz"), mom_slice=mom[:, :, ::17, ::3].numpy().copy(),
+                        mom_checksum=np.asarray(checksum(mom)), z_slice=z[:, :, ::17, ::3].numpy().copy(),
+                        z_checksum=np.asarray(checksum(z)))
+    print("vae enc", checksum(mom), checksum(z))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     assert R.available(), "needs /root/reference"
@@ -226,5 +246,6 @@ if __name__ == "__main__":
     kat_golden()
     unet_golden()
     vae_golden()
+    vae_enc_golden()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -483,6 +483,43 @@ def vae_decode_first_stage(sd: SD, cfg: dict, z: torch.Tensor, prefix: str = "")
 
 
 # ----------------------------------------------------------------------------------------------
+# mel-VAE encoder (autoencoder.py:52-58,112-113,126-135; modules.py:419-543; distributions.py:24-41)
+# ----------------------------------------------------------------------------------------------
+
+def vae_encode_moments(sd: SD, cfg: dict, mel: torch.Tensor, prefix: str = "") -> torch.Tensor:
+    """autoencoder.py:52-58 encode (subband 1: freq_split_subband is the identity) -> modules.py:519-543 Encoder.forward ->
+    quant_conv.  mel [B,1,1024,64] -> moments [B, 2*embed_dim, 256, 16] (= [mean | logvar] along dim 1)."""
+    P = prefix
+    E = P + "encoder."
+    nres = len(cfg["ch_mult"])
+    h = _conv(sd, E + "conv_in", mel)
+    for lvl in range(nres):
+        for b in range(cfg["num_res_blocks"]):
+            h = _vae_resblock(sd, f"{E}down.{lvl}.block.{b}", h)     # attn_resolutions is empty in the Tango VAE config
+        if lvl != nres - 1:                                           # modules.py:87-91: asymmetric (0,1,0,1) pad, k3 s2 p0
+            h = _conv(sd, f"{E}down.{lvl}.downsample.conv", F.pad(h, (0, 1, 0, 1), mode="constant", value=0.0), stride=2, padding=0)
+    h = _vae_resblock(sd, E + "mid.block_1", h)
+    h = _vae_attn(sd, E + "mid.attn_1", h)
+    h = _vae_resblock(sd, E + "mid.block_2", h)
+    h = _conv(sd, E + "conv_out", _swish(_gn(sd, E + "norm_out", h, 32, 1e-6)))
+    return _conv(sd, P + "quant_conv", h, padding=0)
+
+
+def vae_posterior(moments: torch.Tensor):
+    """distributions.py:24-31: (mean, std) with logvar clamped to [-30, 20]."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    return mean, torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+
+
+def vae_get_first_stage_encoding(moments: torch.Tensor, cfg: dict, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """autoencoder.py:126-135 on a DiagonalGaussianDistribution: scale_factor * (mean + std * noise); `noise` is the randn the
+    reference draws inside `sample()` (distributions.py:37-41), None = the posterior mode."""
+    mean, std = vae_posterior(moments)
+    z = mean if noise is None else mean + std * noise
+    return cfg["scale_factor"] * z
+
+
+# ----------------------------------------------------------------------------------------------
 # HiFi-GAN generator (audioldm/hifigan/models.py:96-165) + int16 cast (hifigan/utilities.py:76-86)
 # ----------------------------------------------------------------------------------------------
 

@@ -129,6 +129,41 @@ def _vae_res(out, p, cin, cout):
         out[p + ".nin_shortcut.bias"] = (cout,)
 
 
+def vae_encoder_param_shapes(cfg: dict, prefix: str = "") -> Shapes:
+    """encoder.* + quant_conv (the encode-side subset of pytorch_model_vae.bin; reference modules.py:419-517,
+    autoencoder.py:38).  `attn_resolutions` is empty in the Tango VAE config, so only mid.attn_1 exists."""
+    ch, mult, nrb = cfg["ch"], list(cfg["ch_mult"]), cfg["num_res_blocks"]
+    zc, ed = cfg["z_channels"], cfg.get("embed_dim", 8)
+    out: Shapes = OrderedDict()
+    E = prefix + "encoder."
+    out[E + "conv_in.weight"] = (ch, cfg.get("in_channels", 1), 3, 3)
+    out[E + "conv_in.bias"] = (ch,)
+    bi = ch
+    for lvl in range(len(mult)):
+        bo = ch * mult[lvl]
+        for b in range(nrb):
+            _vae_res(out, f"{E}down.{lvl}.block.{b}", bi, bo)
+            bi = bo
+        if lvl != len(mult) - 1:
+            out[f"{E}down.{lvl}.downsample.conv.weight"] = (bi, bi, 3, 3)
+            out[f"{E}down.{lvl}.downsample.conv.bias"] = (bi,)
+    _vae_res(out, E + "mid.block_1", bi, bi)
+    a = E + "mid.attn_1"
+    out[a + ".norm.weight"] = (bi,)
+    out[a + ".norm.bias"] = (bi,)
+    for n in ("q", "k", "v", "proj_out"):
+        out[f"{a}.{n}.weight"] = (bi, bi, 1, 1)
+        out[f"{a}.{n}.bias"] = (bi,)
+    _vae_res(out, E + "mid.block_2", bi, bi)
+    out[E + "norm_out.weight"] = (bi,)
+    out[E + "norm_out.bias"] = (bi,)
+    out[E + "conv_out.weight"] = (2 * zc, bi, 3, 3)
+    out[E + "conv_out.bias"] = (2 * zc,)
+    out[prefix + "quant_conv.weight"] = (2 * ed, 2 * zc, 1, 1)
+    out[prefix + "quant_conv.bias"] = (2 * ed,)
+    return out
+
+
 def vae_decoder_param_shapes(cfg: dict, prefix: str = "") -> Shapes:
     """post_quant_conv + decoder.* (the decode-side subset of pytorch_model_vae.bin)."""
     ch, mult, nrb = cfg["ch"], list(cfg["ch_mult"]), cfg["num_res_blocks"]

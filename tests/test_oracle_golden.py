@@ -280,6 +280,23 @@ def test_vae_vocoder_match_reference_fixture():
     assert zlib.crc32(wav.tobytes()) == int(z["wav_crc"][0])
 
 
+def test_vae_encoder_matches_reference_fixture():
+    """AutoencoderKL.encode_first_stage / get_first_stage_encoding of the reference (autoencoder.py:52-58,126-135) vs the oracle
+    (SURVEY.md 8f rank 4); the posterior noise is the reference's global-generator draw after manual_seed(5)"""
+    z = np.load(os.path.join(G, "vae_enc_ref.npz"))
+    sd = W.synth_state_dict(W.vae_encoder_param_shapes(O.VAE_CONFIG), 4321)
+    g = torch.Generator().manual_seed(43)
+    mel = torch.randn(2, 1, 1024, 64, generator=g) * 2.0 - 4.0
+    mom = O.vae_encode_moments(sd, O.VAE_CONFIG, mel)
+    assert mom.shape == (2, 16, 256, 16)
+    assert np.abs(mom[:, :, ::17, ::3].numpy() - z["mom_slice"]).max() < 2e-5 * max(1.0, float(np.abs(z["mom_slice"]).max()))
+    torch.manual_seed(5)
+    noise = torch.randn(2, 8, 256, 16)
+    lat = O.vae_get_first_stage_encoding(mom, O.VAE_CONFIG, noise)
+    assert np.abs(lat[:, :, ::17, ::3].numpy() - z["z_slice"]).max() < 2e-5 * max(1.0, float(np.abs(z["z_slice"]).max()))
+    assert np.allclose(checksum(mom), z["mom_checksum"], rtol=1e-5, atol=1e-1)
+
+
 def test_int16_cast_semantics():
     """hifigan/utilities.py:81: truncation toward zero; +1.0 * 32768 wraps to -32768 (x86 numpy)"""
     w = torch.tensor([[0.99999, -0.99999, 0.5 / 32768, -0.5 / 32768, 1.5 / 32768, -1.5 / 32768, -1.0]])

@@ -18,6 +18,8 @@ def test_param_inventories_match_reference_state_dicts():
     ref = {k: tuple(v.shape) for k, v in unet.state_dict().items()}
     assert ref == {k: tuple(v) for k, v in W.unet_param_shapes(O.UNET_CONFIG_LARGE).items()}
     vae = R.autoencoder_cls()(**R.vae_config())
+    enc_ref = {k: tuple(v.shape) for k, v in vae.state_dict().items() if k.startswith(("encoder", "quant_conv"))}
+    assert enc_ref == dict(W.vae_encoder_param_shapes(O.VAE_CONFIG))
     ref = {k: tuple(v.shape) for k, v in vae.state_dict().items() if not k.startswith(("encoder", "quant_conv"))}
     mine = dict(W.vae_decoder_param_shapes(O.VAE_CONFIG))
     mine.update(W.hifigan_param_shapes(O.HIFIGAN_CONFIG))
