@@ -9,6 +9,7 @@
  *                               (+ DDIMScheduler.step                      .../scheduling_ddim.py:238-360)
  *   tango_engine_unet_forward   UNet2DConditionModel.forward               mustango/diffusers/src/diffusers/models/unet_2d_condition.py:520-707
  *   tango_engine_vae_decode     AutoencoderKL.decode_first_stage           audioldm/variational_autoencoder/autoencoder.py:116-124,60-64
+ *   tango_engine_vae_encode     AutoencoderKL.encode (encode_first_stage)  audioldm/variational_autoencoder/autoencoder.py:52-58,112-113
  *   tango_engine_vocode         AutoencoderKL.decode_to_waveform           audioldm/variational_autoencoder/autoencoder.py:66-69
  *                               -> vocoder_infer                           audioldm/hifigan/utilities.py:76-86
  *   tango_engine_set_weight     load_state_dict of pytorch_model_main.bin / pytorch_model_vae.bin   tango.py:22-28
@@ -88,6 +89,10 @@ typedef struct tango_config {
   int32_t t5_d_model, t5_d_kv, t5_heads, t5_d_ff, t5_vocab;   /* d_kv must be 64 */
   int32_t t5_rel_buckets, t5_rel_max_distance;                /* relative_attention_num_buckets (32), _max_distance (128) */
   float t5_eps;                               /* layer_norm_epsilon (1e-6) */
+  /* mel-VAE encoder (modules.py:419-543 + quant_conv, autoencoder.py:38,52-58): built when vae_encoder != 0 (needs the
+   * vae_* fields above); weights are the `encoder.*` / `quant_conv.*` tensors of pytorch_model_vae.bin */
+  int32_t vae_encoder;
+  int32_t vae_in_channels;                    /* ddconfig["in_channels"] (1) */
 } tango_config_t;
 
 typedef struct tango_denoise_args {
@@ -134,6 +139,10 @@ int tango_engine_unet_forward(tango_engine_t* h, const float* sample, int64_t ti
 
 /* latents [B,8,256,16] fp32 -> mel [B,1,1024,64] fp32 */
 int tango_engine_vae_decode(tango_engine_t* h, const float* latents, float* mel, int batch, void* stream);
+/* AutoencoderKL.encode (autoencoder.py:52-58: Encoder.forward, modules.py:519-543, then quant_conv): mel [B, in_ch, 4H, 4W] fp32
+ * NCHW (H, W = latent_h, latent_w for three levels) -> moments [B, 2*embed_dim, H, W] fp32 NCHW = [mean | logvar]; the posterior
+ * (clamp, exp, sample: distributions.py:24-41) and scale_factor (autoencoder.py:126-135) are host-side code of the caller */
+int tango_engine_vae_encode(tango_engine_t* h, const float* mel, float* moments, int batch, void* stream);
 /* mel [B,1,T,num_mels] fp32 -> int16 [B, samples]; returns samples per item via *n_samples (may be NULL) */
 int tango_engine_vocode(tango_engine_t* h, const float* mel, int16_t* wav, int batch, int mel_frames, int* n_samples, void* stream);
 int tango_engine_vocoder_samples(tango_engine_t* h, int mel_frames);

@@ -58,6 +58,8 @@ class TangoConfig(C.Structure):
         ("t5_rel_buckets", C.c_int32),
         ("t5_rel_max_distance", C.c_int32),
         ("t5_eps", C.c_float),
+        ("vae_encoder", C.c_int32),
+        ("vae_in_channels", C.c_int32),
     ]
 
 
@@ -88,7 +90,7 @@ SYMBOLS = [
     "tango_last_error", "tango_version", "tango_engine_create", "tango_engine_destroy",
     "tango_engine_num_weights", "tango_engine_weight_name", "tango_engine_set_weight",
     "tango_engine_finalize_weights", "tango_engine_denoise", "tango_engine_unet_forward",
-    "tango_engine_vae_decode", "tango_engine_vocode", "tango_engine_vocoder_samples", "tango_engine_encode_text",
+    "tango_engine_vae_decode", "tango_engine_vae_encode", "tango_engine_vocode", "tango_engine_vocoder_samples", "tango_engine_encode_text",
     "tango_engine_last_denoise_ms", "tango_engine_profile_unet", "tango_op_conv2d", "tango_op_linear", "tango_op_linear_ln", "tango_op_linear_qkv", "tango_op_conv1d",
     "tango_op_conv_transpose1d", "tango_op_groupnorm", "tango_op_layernorm", "tango_op_attention",
     "tango_op_sched_step", "tango_op_philox_normal",
@@ -121,6 +123,7 @@ def load():
     lib.tango_engine_denoise.argtypes = [vp, C.POINTER(DenoiseArgs), vp]
     lib.tango_engine_unet_forward.argtypes = [vp, vp, i64, vp, vp, vp, ci, ci, vp]
     lib.tango_engine_vae_decode.argtypes = [vp, vp, vp, ci, vp]
+    lib.tango_engine_vae_encode.argtypes = [vp, vp, vp, ci, vp]
     lib.tango_engine_vocode.argtypes = [vp, vp, vp, ci, ci, C.POINTER(ci), vp]
     lib.tango_engine_vocoder_samples.argtypes = [vp, ci]
     lib.tango_engine_encode_text.argtypes = [vp, vp, vp, vp, ci, ci, vp]

@@ -150,6 +150,7 @@ struct GemmParams {
   int mode = GATHER_1D;
   // 2D: output grid H x W per image; source image Hin x Win (conv input is source upsampled if ups)
   int H = 0, Wd = 0, Hin = 0, Win = 0, stride = 1, ups = 0;
+  int pad = 1;                 // GATHER_2D: top / left zero padding (1 = symmetric 3x3 "same"; 0 = the VAE Downsample's (0,1,0,1) pad)
   // 1D: rows_pb output rows per batch item; source length Lin; index = q*in_mul + in_off + tap*tap_step
   int rows_pb = 0, Lin = 0, taps = 1, tap_step = 1, in_off = 0, in_mul = 1;
   int Lout = 0, out_mul = 1, out_off = 0;  // out row = b*Lout + q*out_mul + out_off
@@ -285,6 +286,8 @@ int launch_pack(int dtype, const float* src, void* dst, int O, int Tn, int I, in
                 int64_t Kp, int64_t dst_row_off, hipStream_t s);
 int launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 // lat f32 NCHW [B,Cin,HW] * scale -> 1x1 conv (W f32 [Cout][Cin], b) -> T NHWC [B*HW][ld]
+int launch_pointwise_out_nchw(const float* src, int64_t ld, const float* W, const float* b, float* dst, int B, int Cin, int Cout, int HW,
+                              hipStream_t s);   // fp32 rows [B*HW][ld] -> 1x1 conv -> fp32 NCHW [B][Cout][HW] (quant_conv)
 int launch_pointwise_small(int dtype, const float* src, const float* W, const float* b, void* dst, int64_t ld, int B, int Cin,
                            int Cout, int HW, float scale, hipStream_t s);
 int launch_permute_geglu_bias(const float* src, float* dst, int n, hipStream_t s);

@@ -315,7 +315,7 @@ bool conv_halo_ok(int dtype, const GemmParams& p) {
   static const bool off = getenv("TANGO_NO_HALO_CONV") != nullptr;      // experiment switch
   if (off) return false;
   const int esz = dtype == DT_F32 ? 4 : 2;
-  if (p.mode != GATHER_2D || p.stride != 1 || p.ups < 0 || p.ups > 1 || (p.Hin << p.ups) != p.H || (p.Win << p.ups) != p.Wd) return false;
+  if (p.mode != GATHER_2D || p.stride != 1 || p.pad != 1 || p.ups < 0 || p.ups > 1 || (p.Hin << p.ups) != p.H || (p.Win << p.ups) != p.Wd) return false;
   if (p.batch != 1 || p.splitk > 1 || p.a_act != ACT_NONE || p.epi == EPI_GEGLU || p.epi == EPI_VT) return false;
   if ((p.Cin * esz) % 128 != 0 || p.K != 9 * p.Cin || p.M % 256 != 0) return false;
   const int bn = p.N % 160 == 0 ? 160 : 128;

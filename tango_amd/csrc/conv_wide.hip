@@ -242,7 +242,7 @@ static bool wide_halo_geom(const GemmParams& p, WideHaloGeom& g) {
 bool conv_wide_ok(int dtype, const GemmParams& p) {
   static const bool off = getenv("TANGO_NO_WIDE_CONV") != nullptr;      // experiment switch
   if (off || dtype == DT_F32) return false;
-  if (p.mode != GATHER_2D || p.stride != 1 || p.ups < 0 || p.ups > 1 || (p.Hin << p.ups) != p.H || (p.Win << p.ups) != p.Wd) return false;
+  if (p.mode != GATHER_2D || p.stride != 1 || p.pad != 1 || p.ups < 0 || p.ups > 1 || (p.Hin << p.ups) != p.H || (p.Win << p.ups) != p.Wd) return false;
   if (p.batch != 1 || p.a_act != ACT_NONE || p.epi != EPI_NONE || p.bias_rows) return false;
   if (p.splitk > 1 ? (!p.ws || p.splitk > p.Cin / 32 || p.N % 4 != 0) : (p.e_act != ACT_NONE || p.out_f32)) return false;
   if ((p.Cin * 2) % 64 != 0 || p.K != 9 * p.Cin || p.M % 256 != 0 || p.N % 320 != 0) return false;

@@ -383,6 +383,31 @@ int launch_pointwise_small(int dtype, const float* src, const float* W, const fl
   return 0;
 }
 
+// VAE encoder tail: moments = quant_conv(h) (autoencoder.py:56), 1x1 conv with tiny C on fp32 channels-last rows, written in
+// the reference's NCHW fp32 layout
+__global__ __launch_bounds__(256) void pointwise_out_nchw_kernel(const float* __restrict__ src, int64_t ld, const float* __restrict__ W,
+                                                                 const float* __restrict__ bias, float* __restrict__ dst, int B, int Cin,
+                                                                 int Cout, int HW) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * HW) return;
+  const int b = (int)(idx / HW), hw = (int)(idx - (int64_t)b * HW);
+  float x[32];
+  for (int c = 0; c < Cin; ++c) x[c] = src[idx * ld + c];
+  for (int o = 0; o < Cout; ++o) {
+    float a = bias ? bias[o] : 0.f;
+    for (int c = 0; c < Cin; ++c) a += W[o * Cin + c] * x[c];
+    dst[((int64_t)b * Cout + o) * HW + hw] = a;
+  }
+}
+int launch_pointwise_out_nchw(const float* src, int64_t ld, const float* W, const float* b, float* dst, int B, int Cin, int Cout, int HW,
+                              hipStream_t s) {
+  if (Cin > 32) TANGO_FAIL("pointwise_out_nchw: Cin > 32");
+  const unsigned nb = (unsigned)(((int64_t)B * HW + 255) / 256);
+  hipLaunchKernelGGL(pointwise_out_nchw_kernel, dim3(nb), dim3(256), 0, s, src, ld, W, b, dst, B, Cin, Cout, HW);
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
 __global__ void permute_geglu_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) dst[geglu_row(i, n / 2)] = src[i];

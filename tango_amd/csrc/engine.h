@@ -152,6 +152,7 @@ class Engine {
   int denoise(const tango_denoise_args_t& a, hipStream_t s);
   int unet_forward(const float* sample, int64_t t, const float* enc, const uint8_t* mask, float* out, int B2, int L, hipStream_t s);
   int vae_decode(const float* lat, float* mel, int B, hipStream_t s);
+  int vae_encode(const float* mel, float* moments, int B, hipStream_t s);
   int vocode(const float* mel, int16_t* wav, int B, int frames, int* n_samples, hipStream_t s);
   int vocoder_samples(int frames) const;
   int encode_text(const int64_t* ids, const uint8_t* mask, float* out, int B, int L, hipStream_t s);
@@ -187,6 +188,8 @@ class Engine {
   int fold_ln(WMat& w, const WNorm& ln);
   void build_unet_weights();
   void build_vae_weights();
+  void build_vae_enc_weights();
+  void reg_vae_attn(const std::string& p, int C, VaeAttnW& w);
   void build_voc_weights();
   void build_t5_weights();
 
@@ -211,6 +214,14 @@ class Engine {
   struct VaeUp { std::vector<ResW> res; bool has_up = false; WMat up; };
   std::vector<VaeUp> vae_up;    // indexed by level
   WNorm vae_norm_out;
+  // encoder (modules.py:419-543) + quant_conv
+  struct VaeDown { std::vector<ResW> res; bool has_down = false; WMat down; };
+  std::vector<VaeDown> vae_down;
+  WMat vae_enc_conv_in, vae_enc_conv_out;
+  ResW vae_enc_mid1, vae_enc_mid2;
+  VaeAttnW vae_enc_attn;
+  WNorm vae_enc_norm_out;
+  float* qc_w = nullptr; float* qc_b = nullptr;
   // vocoder
   WMat voc_pre, voc_post;
   std::vector<ConvTW> voc_ups;
@@ -237,6 +248,7 @@ class Engine {
   int max_steps = 1000;
   std::map<std::pair<int, int>, std::unique_ptr<UNetPlan>> unet_plans;
   std::map<int, std::unique_ptr<VaePlan>> vae_plans;
+  std::map<int, std::unique_ptr<VaePlan>> vae_enc_plans;
   std::map<std::pair<int, int>, std::unique_ptr<VaePlan>> voc_plans;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t cap_stream = nullptr;
@@ -247,6 +259,8 @@ class Engine {
   int build_unet(UNetPlan& P, Arena& A, bool record);
   int get_vae_plan(int B, VaePlan** out);
   int build_vae(VaePlan& P, Arena& A, bool record);
+  int get_vae_enc_plan(int B, VaePlan** out);
+  int build_vae_enc(VaePlan& P, Arena& A, bool record);
   int get_voc_plan(int B, int frames, VaePlan** out);
   int build_voc(VaePlan& P, Arena& A, bool record, int frames);
   int bind_text(UNetPlan& P, const float* enc, const uint8_t* mask, hipStream_t s);

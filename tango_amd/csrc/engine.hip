@@ -37,6 +37,7 @@ struct GOpt {
   int64_t vt_ld = 0;
   const WNorm* ln = nullptr;     // apply LayerNorm(ln) to the input rows first (folded when the streaming kernel applies)
   int glu_tanh = 0;              // EPI_GEGLU gate: tanh GELU (T5 gated-gelu) instead of exact-erf GELU
+  int pad = 1;                   // conv3x3: top / left zero padding (0 = the VAE Downsample's asymmetric (0,1,0,1) pad)
 };
 
 struct Builder {
@@ -134,7 +135,7 @@ struct Builder {
     GemmParams p;
     p.A = x.p; p.lda = x.ld; p.W = w.W; p.Kp = w.Kp; p.bias = o.use_bias ? w.b : nullptr;
     p.M = B * H * W; p.N = w.N; p.K = w.K; p.Cin = w.Cin;
-    p.mode = GATHER_2D; p.H = H; p.Wd = W; p.Hin = Hin; p.Win = Win; p.stride = stride; p.ups = ups;
+    p.mode = GATHER_2D; p.H = H; p.Wd = W; p.Hin = Hin; p.Win = Win; p.stride = stride; p.ups = ups; p.pad = o.pad;
     p.out = out.p; p.ldo = out.ld; p.out_f32 = o.out_f32;
     if (o.residual) { p.R = o.residual->p; p.ldr = o.residual->ld; }
     p.a_act = o.a_act; p.a_slope = o.a_slope; p.e_act = o.e_act; p.e_slope = o.e_slope; p.epi = o.epi;
@@ -197,6 +198,48 @@ struct Builder {
     o2.residual = &R;
     conv3x3(t2, B, H, W, H, W, 1, 0, w.c2, out, o2);
     A.release(m);
+  }
+
+  // VAE AttnBlock (modules.py:204-230): single head, d = C, scale C^-0.5; returns x + proj_out(attention(norm(x)))
+  TView vae_attn(const VaeAttnW& w, const TView& h, int B, int HW, int C) {
+    const int64_t rows = (int64_t)B * HW;
+    TView hn = alloc(rows, C);
+    groupnorm(h, B, HW, w.gn, 32, ACT_NONE, hn);
+    TView qk = alloc(rows, 2 * C);
+    linear(hn, rows, w.qk, qk);
+    // V^T[b][c][s] = Wv[c,:] . hn[b,s,:] + bv[c]   (weights as the row operand, tokens as columns)
+    TView vt = alloc((int64_t)B * C, HW);
+    {
+      GemmParams p;
+      p.A = w.v.W; p.lda = w.v.Kp; p.W = hn.p; p.Kp = hn.ld; p.bias = w.v.b; p.bias_rows = 1;
+      p.M = C; p.N = HW; p.K = C; p.Cin = C; p.mode = GATHER_1D; p.rows_pb = C; p.Lin = C; p.Lout = C; p.taps = 1;
+      p.out = vt.p; p.ldo = HW; p.batch = B; p.sA = 0; p.sW = (int64_t)HW * hn.ld; p.sO = (int64_t)C * HW;
+      gemm(p);
+    }
+    TView sc = alloc((int64_t)B * HW, HW);
+    {
+      GemmParams p;
+      p.A = qk.p; p.lda = qk.ld; p.W = (char*)qk.p + (size_t)C * esz; p.Kp = qk.ld;
+      p.M = HW; p.N = HW; p.K = C; p.Cin = C; p.mode = GATHER_1D; p.rows_pb = HW; p.Lin = HW; p.Lout = HW; p.taps = 1;
+      p.out = sc.p; p.ldo = HW; p.alpha = 1.0f / std::sqrt((float)C);
+      p.batch = B; p.sA = (int64_t)HW * qk.ld; p.sW = (int64_t)HW * qk.ld; p.sO = (int64_t)HW * HW;
+      gemm(p);
+    }
+    {
+      const int d = dt; void* x = sc.p; const int r = B * HW, c = HW;
+      push([=](hipStream_t s) { return launch_softmax_rows(d, x, c, r, c, 1.0f, s); });
+    }
+    TView ao = alloc(rows, C);
+    {
+      GemmParams p;
+      p.A = sc.p; p.lda = HW; p.W = vt.p; p.Kp = HW;
+      p.M = HW; p.N = C; p.K = HW; p.Cin = HW; p.mode = GATHER_1D; p.rows_pb = HW; p.Lin = HW; p.Lout = HW; p.taps = 1;
+      p.out = ao.p; p.ldo = C; p.batch = B; p.sA = (int64_t)HW * HW; p.sW = (int64_t)C * HW; p.sO = (int64_t)HW * C;
+      gemm(p);
+    }
+    TView o = hn;   // reuse: the normalised copy is dead; the other temporaries (small next to the 1024 x 64 activations) stay allocated
+    { GOpt go; go.residual = &h; linear(ao, rows, w.proj, o, go); }
+    return o;
   }
 
   // Transformer2DModel (transformer_2d.py:214-321) + BasicTransformerBlock (attention.py:276-335)
@@ -512,22 +555,7 @@ void Engine::build_vae_weights() {
   int bi = ch * cfg.vae_ch_mult[nl - 1];
   reg_conv3x3(D + "conv_in", bi, zc, vae_conv_in);
   reg_res(D + "mid.block_1", bi, bi, 0, 1e-6f, vae_mid1, true);
-  reg_norm(D + "mid.attn_1.norm", bi, 1e-6f, vae_attn.gn);
-  // fused [q; k] 1x1 convs; v and proj_out separate
-  vae_attn.qk.N = 2 * bi; vae_attn.qk.K = bi; vae_attn.qk.Cin = bi; vae_attn.qk.Kp = bi; vae_attn.qk.taps = 1;
-  vae_attn.qk.W = dmalloc((size_t)2 * bi * bi * esz);
-  vae_attn.qk.b = (float*)dmalloc((size_t)2 * bi * 4);
-  reg_mat(D + "mid.attn_1.q.weight", bi, bi, vae_attn.qk, false, 0, {bi, bi, 1, 1});
-  reg_mat(D + "mid.attn_1.k.weight", bi, bi, vae_attn.qk, false, bi, {bi, bi, 1, 1});
-  {
-    float* b0 = vae_attn.qk.b;
-    float* b1 = vae_attn.qk.b + bi;
-    const size_t n = (size_t)bi * 4;
-    reg_slot(D + "mid.attn_1.q.bias", {bi}, [b0, n](const float* src, hipStream_t s) { TANGO_HIP(hipMemcpyAsync(b0, src, n, hipMemcpyDeviceToDevice, s)); return 0; });
-    reg_slot(D + "mid.attn_1.k.bias", {bi}, [b1, n](const float* src, hipStream_t s) { TANGO_HIP(hipMemcpyAsync(b1, src, n, hipMemcpyDeviceToDevice, s)); return 0; });
-  }
-  reg_conv1x1(D + "mid.attn_1.v", bi, bi, vae_attn.v);
-  reg_conv1x1(D + "mid.attn_1.proj_out", bi, bi, vae_attn.proj);
+  reg_vae_attn(D + "mid.attn_1", bi, vae_attn);
   reg_res(D + "mid.block_2", bi, bi, 0, 1e-6f, vae_mid2, true);
   vae_up.resize(nl);
   for (int lvl = nl - 1; lvl >= 0; --lvl) {
@@ -545,6 +573,63 @@ void Engine::build_vae_weights() {
   }
   reg_norm(D + "norm_out", bi, 1e-6f, vae_norm_out);
   reg_conv3x3(D + "conv_out", cfg.vae_out_ch, bi, vae_conv_out);
+}
+
+void Engine::reg_vae_attn(const std::string& a, int bi, VaeAttnW& w) {
+  reg_norm(a + ".norm", bi, 1e-6f, w.gn);
+  // fused [q; k] 1x1 convs; v and proj_out separate
+  w.qk.N = 2 * bi; w.qk.K = bi; w.qk.Cin = bi; w.qk.Kp = bi; w.qk.taps = 1;
+  w.qk.W = dmalloc((size_t)2 * bi * bi * esz);
+  w.qk.b = (float*)dmalloc((size_t)2 * bi * 4);
+  reg_mat(a + ".q.weight", bi, bi, w.qk, false, 0, {bi, bi, 1, 1});
+  reg_mat(a + ".k.weight", bi, bi, w.qk, false, bi, {bi, bi, 1, 1});
+  {
+    float* b0 = w.qk.b;
+    float* b1 = w.qk.b + bi;
+    const size_t n = (size_t)bi * 4;
+    reg_slot(a + ".q.bias", {bi}, [b0, n](const float* src, hipStream_t s) { TANGO_HIP(hipMemcpyAsync(b0, src, n, hipMemcpyDeviceToDevice, s)); return 0; });
+    reg_slot(a + ".k.bias", {bi}, [b1, n](const float* src, hipStream_t s) { TANGO_HIP(hipMemcpyAsync(b1, src, n, hipMemcpyDeviceToDevice, s)); return 0; });
+  }
+  reg_conv1x1(a + ".v", bi, bi, w.v);
+  reg_conv1x1(a + ".proj_out", bi, bi, w.proj);
+}
+
+// mel-VAE encoder weights: encoder.* + quant_conv (modules.py:419-517, autoencoder.py:38)
+void Engine::build_vae_enc_weights() {
+  const int nl = cfg.vae_levels, ch = cfg.vae_ch, zc = cfg.vae_z_channels, ed = cfg.vae_embed_dim;
+  const int cin = cfg.vae_in_channels > 0 ? cfg.vae_in_channels : 1;
+  const std::string E = "encoder.";
+  reg_conv3x3(E + "conv_in", ch, cin, vae_enc_conv_in);
+  vae_down.resize(nl);
+  int bi = ch;
+  for (int lvl = 0; lvl < nl; ++lvl) {
+    const int bo = ch * cfg.vae_ch_mult[lvl];
+    VaeDown& d = vae_down[lvl];
+    d.res.resize(cfg.vae_num_res_blocks);
+    for (int b = 0; b < cfg.vae_num_res_blocks; ++b) {
+      reg_res(E + "down." + std::to_string(lvl) + ".block." + std::to_string(b), bi, bo, 0, 1e-6f, d.res[b], true);
+      bi = bo;
+    }
+    if (lvl != nl - 1) {
+      d.has_down = true;
+      reg_conv3x3(E + "down." + std::to_string(lvl) + ".downsample.conv", bi, bi, d.down);
+    }
+  }
+  reg_res(E + "mid.block_1", bi, bi, 0, 1e-6f, vae_enc_mid1, true);
+  reg_vae_attn(E + "mid.attn_1", bi, vae_enc_attn);
+  reg_res(E + "mid.block_2", bi, bi, 0, 1e-6f, vae_enc_mid2, true);
+  reg_norm(E + "norm_out", bi, 1e-6f, vae_enc_norm_out);
+  reg_conv3x3(E + "conv_out", 2 * zc, bi, vae_enc_conv_out);
+  qc_w = (float*)dmalloc((size_t)2 * ed * 2 * zc * 4);
+  {
+    float* d = qc_w;
+    const size_t n = (size_t)2 * ed * 2 * zc;
+    reg_slot("quant_conv.weight", {2 * ed, 2 * zc, 1, 1}, [d, n](const float* src, hipStream_t s) {
+      TANGO_HIP(hipMemcpyAsync(d, src, n * 4, hipMemcpyDeviceToDevice, s));
+      return 0;
+    });
+  }
+  reg_vec("quant_conv.bias", 2 * ed, &qc_b);
 }
 
 void Engine::build_voc_weights() {
@@ -590,6 +675,10 @@ int Engine::init() {
     if (!d_step || !d_sched || !d_ts || !d_coef || !d_sin || !d_t1 || !d_temb) return -1;
   }
   if (cfg.vae_levels > 0) build_vae_weights();
+  if (cfg.vae_levels > 0 && cfg.vae_encoder) {
+    if (2 * cfg.vae_z_channels > 32) TANGO_FAIL("engine: VAE encoder with 2 * z_channels > 32 is not supported (quant_conv kernel)");
+    build_vae_enc_weights();
+  }
   if (cfg.voc_n_ups > 0) build_voc_weights();
   if (cfg.t5_layers > 0) {
     if (cfg.t5_d_kv != 64) TANGO_FAIL("engine: T5 d_kv must be 64 (attention head_dim)");
@@ -1127,51 +1216,7 @@ int Engine::build_vae(VaePlan& P, Arena& A, bool record) {
     b.resblock(vae_mid1, h, B, H0, W0, 32, o);
     h = o;
   }
-  {  // AttnBlock (modules.py:204-230): single head, d = C
-    const size_t m = A.mark();
-    const int64_t rows = (int64_t)B * HW0;
-    TView hn = b.alloc(rows, C);
-    b.groupnorm(h, B, HW0, vae_attn.gn, 32, ACT_NONE, hn);
-    TView qk = b.alloc(rows, 2 * C);
-    b.linear(hn, rows, vae_attn.qk, qk);
-    // V^T[b][c][s] = Wv[c,:] . hn[b,s,:] + bv[c]   (weights as the row operand, tokens as columns)
-    TView vt = b.alloc((int64_t)B * C, HW0);
-    {
-      GemmParams p;
-      p.A = vae_attn.v.W; p.lda = vae_attn.v.Kp; p.W = hn.p; p.Kp = hn.ld; p.bias = vae_attn.v.b; p.bias_rows = 1;
-      p.M = C; p.N = HW0; p.K = C; p.Cin = C; p.mode = GATHER_1D; p.rows_pb = C; p.Lin = C; p.Lout = C; p.taps = 1;
-      p.out = vt.p; p.ldo = HW0; p.batch = B; p.sA = 0; p.sW = (int64_t)HW0 * hn.ld; p.sO = (int64_t)C * HW0;
-      b.gemm(p);
-    }
-    TView sc = b.alloc((int64_t)B * HW0, HW0);
-    {
-      GemmParams p;
-      p.A = qk.p; p.lda = qk.ld; p.W = (char*)qk.p + (size_t)C * esz; p.Kp = qk.ld;
-      p.M = HW0; p.N = HW0; p.K = C; p.Cin = C; p.mode = GATHER_1D; p.rows_pb = HW0; p.Lin = HW0; p.Lout = HW0; p.taps = 1;
-      p.out = sc.p; p.ldo = HW0; p.alpha = 1.0f / std::sqrt((float)C);
-      p.batch = B; p.sA = (int64_t)HW0 * qk.ld; p.sW = (int64_t)HW0 * qk.ld; p.sO = (int64_t)HW0 * HW0;
-      b.gemm(p);
-    }
-    {
-      const int d = dt; void* x = sc.p; const int r = B * HW0, c = HW0;
-      b.push([=](hipStream_t s) { return launch_softmax_rows(d, x, c, r, c, 1.0f, s); });
-    }
-    TView ao = b.alloc(rows, C);
-    {
-      GemmParams p;
-      p.A = sc.p; p.lda = HW0; p.W = vt.p; p.Kp = HW0;
-      p.M = HW0; p.N = C; p.K = HW0; p.Cin = HW0; p.mode = GATHER_1D; p.rows_pb = HW0; p.Lin = HW0; p.Lout = HW0; p.taps = 1;
-      p.out = ao.p; p.ldo = C; p.batch = B; p.sA = (int64_t)HW0 * HW0; p.sW = (int64_t)C * HW0; p.sO = (int64_t)HW0 * C;
-      b.gemm(p);
-    }
-    TView o = hn;   // reuse
-    { GOpt go; go.residual = &h; b.linear(ao, rows, vae_attn.proj, o, go); }
-    // keep `o` alive: copy view out of the released region by allocating the result before the temps
-    // would be cleaner; instead we simply do not release (the attention temporaries are small vs the
-    // later 1024x64 activations).
-    h = o;
-    (void)m;
-  }
+  h = b.vae_attn(vae_attn, h, B, HW0, C);
   {
     TView o = b.alloc((int64_t)B * HW0, C);
     b.resblock(vae_mid2, h, B, H0, W0, 32, o);
@@ -1226,6 +1271,97 @@ int Engine::vae_decode(const float* lat, float* mel, int B, hipStream_t s) {
   TANGO_HIP(hipMemcpyAsync(P->in, lat, P->in_bytes, hipMemcpyDeviceToDevice, s));
   TANGO_TRY(P->prog.run(s));
   TANGO_HIP(hipMemcpyAsync(mel, P->out, P->out_bytes, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+// ================================================================================================
+// mel-VAE encoder plan (autoencoder.py:52-58 -> modules.py:519-543 Encoder.forward -> quant_conv): mel [B, 1, 4H, 4W] fp32 ->
+// moments [B, 2 * embed_dim, H, W] fp32 NCHW.  Same operators as the decoder; the Downsample convs are stride-2 gathers with the
+// reference's asymmetric (0,1,0,1) zero padding (GemmParams::pad = 0).
+// ================================================================================================
+int Engine::build_vae_enc(VaePlan& P, Arena& A, bool record) {
+  Builder b{*this, A, &P.prog, record, dt, esz};
+  const int B = P.B, nl = cfg.vae_levels;
+  const int cin = cfg.vae_in_channels > 0 ? cfg.vae_in_channels : 1;
+  int Hc = cfg.latent_h << (nl - 1), Wc = cfg.latent_w << (nl - 1);
+  const int HW0 = cfg.latent_h * cfg.latent_w;
+  P.in_bytes = (size_t)B * cin * Hc * Wc * 4;
+  P.in = A.alloc(P.in_bytes);
+  P.out_bytes = (size_t)B * 2 * cfg.vae_embed_dim * HW0 * 4;
+  P.out = A.alloc(P.out_bytes);
+  if (cin != 1) TANGO_FAIL("engine: VAE encoder in_channels must be 1 (NCHW == NHWC at the boundary)");
+
+  TView x = b.alloc((int64_t)B * Hc * Wc, cin);
+  {
+    const int d = dt; const float* src = (const float*)P.in; void* dst = x.p; const int rows = B * Hc * Wc;
+    b.push([=](hipStream_t s) { return launch_cast_rows(d, src, dst, 1, rows, 1, s); });
+  }
+  int C = vae_enc_conv_in.N;
+  TView h = b.alloc((int64_t)B * Hc * Wc, C);
+  b.conv3x3(x, B, Hc, Wc, Hc, Wc, 1, 0, vae_enc_conv_in, h);
+  for (int lvl = 0; lvl < nl; ++lvl) {
+    for (size_t k = 0; k < vae_down[lvl].res.size(); ++k) {
+      const ResW& r = vae_down[lvl].res[k];
+      TView o = b.alloc((int64_t)B * Hc * Wc, r.cout);
+      b.resblock(r, h, B, Hc, Wc, 32, o);
+      h = o; C = r.cout;
+    }
+    if (vae_down[lvl].has_down) {
+      TView o = b.alloc((int64_t)B * (Hc / 2) * (Wc / 2), C);
+      GOpt go; go.pad = 0;                                  // F.pad(x, (0,1,0,1)) + conv(k3, s2, p0), modules.py:87-91
+      b.conv3x3(h, B, Hc / 2, Wc / 2, Hc, Wc, 2, 0, vae_down[lvl].down, o, go);
+      h = o; Hc /= 2; Wc /= 2;
+    }
+  }
+  {
+    TView o = b.alloc((int64_t)B * HW0, C);
+    b.resblock(vae_enc_mid1, h, B, Hc, Wc, 32, o);
+    h = o;
+  }
+  h = b.vae_attn(vae_enc_attn, h, B, HW0, C);
+  {
+    TView o = b.alloc((int64_t)B * HW0, C);
+    b.resblock(vae_enc_mid2, h, B, Hc, Wc, 32, o);
+    h = o;
+  }
+  {
+    TView t = b.alloc((int64_t)B * HW0, C);
+    b.groupnorm(h, B, HW0, vae_enc_norm_out, 32, ACT_SILU, t);
+    const int mc = 2 * cfg.vae_z_channels;
+    float* mom = b.alloc_f32((size_t)B * HW0 * mc);
+    TView o; o.p = mom; o.ld = mc; o.C = mc;
+    GOpt go; go.out_f32 = true;
+    b.conv3x3(t, B, Hc, Wc, Hc, Wc, 1, 0, vae_enc_conv_out, o, go);
+    const float* W = qc_w; const float* bb = qc_b; float* dst = (float*)P.out; const int co = 2 * cfg.vae_embed_dim;
+    b.push([=](hipStream_t s) { return launch_pointwise_out_nchw(mom, mc, W, bb, dst, B, mc, co, HW0, s); });
+  }
+  return 0;
+}
+
+int Engine::get_vae_enc_plan(int B, VaePlan** out) {
+  auto it = vae_enc_plans.find(B);
+  if (it != vae_enc_plans.end()) { *out = it->second.get(); return 0; }
+  if (!finalized) TANGO_FAIL("engine: weights not finalized");
+  std::unique_ptr<VaePlan> P(new VaePlan());
+  P->B = B;
+  Arena m;
+  TANGO_TRY(build_vae_enc(*P, m, false));
+  TANGO_HIP(hipMalloc((void**)&P->slab, m.peak + 256));
+  Arena a; a.base = P->slab;
+  P->prog.ops.clear();
+  TANGO_TRY(build_vae_enc(*P, a, true));
+  *out = P.get();
+  vae_enc_plans[B] = std::move(P);
+  return 0;
+}
+
+int Engine::vae_encode(const float* mel, float* moments, int B, hipStream_t s) {
+  if (cfg.vae_levels <= 0 || !cfg.vae_encoder) TANGO_FAIL("engine: VAE encoder not configured (tango_config.vae_encoder)");
+  VaePlan* P;
+  TANGO_TRY(get_vae_enc_plan(B, &P));
+  TANGO_HIP(hipMemcpyAsync(P->in, mel, P->in_bytes, hipMemcpyDeviceToDevice, s));
+  TANGO_TRY(P->prog.run(s));
+  TANGO_HIP(hipMemcpyAsync(moments, P->out, P->out_bytes, hipMemcpyDeviceToDevice, s));
   return 0;
 }
 
@@ -1406,6 +1542,9 @@ int tango_engine_denoise(tango_engine_t* h, const tango_denoise_args_t* a, void*
 int tango_engine_unet_forward(tango_engine_t* h, const float* sample, int64_t timestep, const float* prompt_embeds,
                               const uint8_t* prompt_mask, float* out, int batch2, int text_len, void* stream) {
   return h->e->unet_forward(sample, timestep, prompt_embeds, prompt_mask, out, batch2, text_len, (hipStream_t)stream);
+}
+int tango_engine_vae_encode(tango_engine_t* h, const float* mel, float* moments, int batch, void* stream) {
+  return h->e->vae_encode(mel, moments, batch, (hipStream_t)stream);
 }
 int tango_engine_vae_decode(tango_engine_t* h, const float* latents, float* mel, int batch, void* stream) {
   return h->e->vae_decode(latents, mel, batch, (hipStream_t)stream);

@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256, (BKB == 64 ? 3 : 2)) void gemm_kernel(const Ge
         const int b = m / hw, rem = m - b * hw;
         const int y = rem / p.Wd, x = rem - y * p.Wd;
         a_base[i] = (int64_t)b * p.Hin * p.Win;
-        a_c0[i] = y * p.stride - 1;
-        a_c1[i] = x * p.stride - 1;
+        a_c0[i] = y * p.stride - p.pad;
+        a_c1[i] = x * p.stride - p.pad;
       } else {
         const int b = m / p.rows_pb, q = m - b * p.rows_pb;
         a_base[i] = (int64_t)b * p.Lin;

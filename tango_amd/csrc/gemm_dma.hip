@@ -72,8 +72,8 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GemmParams p, co
             const int b = m / hw, rem = m - b * hw;
             const int y = rem / p.Wd, x = rem - y * p.Wd;
             r_base[i] = (int64_t)b * p.Hin * p.Win;
-            r_c0[i] = y * p.stride - 1;
-            r_c1[i] = x * p.stride - 1;
+            r_c0[i] = y * p.stride - p.pad;
+            r_c1[i] = x * p.stride - p.pad;
           } else {
             const int b = m / p.rows_pb, q = m - b * p.rows_pb;
             r_base[i] = (int64_t)b * p.Lin;

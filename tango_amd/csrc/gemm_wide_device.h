@@ -40,7 +40,7 @@ __device__ __forceinline__ f32x4 wide_col_value(const f32x4 av, const float mean
 template <typename T, bool GEGLU, bool RES, bool LN>
 __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[10][4], const float (&mean)[4], const float (&rstd)[4],
                                               const int m_base, const int n_base, const int lane, unsigned char* stage) {
-  constexpr int TN = 10, TM = 4, NIT = 5;
+  constexpr int TN = 10, NIT = 5;
   constexpr int OC = GEGLU ? 80 : 160;                 // output columns of this wave
   constexpr int PITCH = OC * 4 + 16;                   // fp32 staging row
   constexpr int PPR = OC / 8;                          // 16-byte output pieces per row

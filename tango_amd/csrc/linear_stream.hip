@@ -159,7 +159,6 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
   // weight-fragment offsets: row n_local = tn*16 + l15 -> (row & 7) == (lane & 7)
   const unsigned char* wbase = wlds + l15 * ROWB;
   const int sw = lane & 7;
-  const float* bias = p.bias;
   const int g4 = g * 4;
   auto koff_of = [&](int ks) -> int { return (ks >> 1) * 128 + ((((ks & 1) * 4 + g) ^ sw) * 16); };
 

@@ -53,7 +53,7 @@ class Engine:
     """One engine handle = one (device, model) pair; not re-entrant (include/tango_engine.h)."""
 
     def __init__(self, unet: Optional[dict] = None, vae: Optional[dict] = None, hifigan: Optional[dict] = None,
-                 dtype: str = "fp16", device="cuda:0", t5: Optional[dict] = None):
+                 dtype: str = "fp16", device="cuda:0", t5: Optional[dict] = None, vae_encoder: bool = False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("tango_amd.Engine needs a HIP device (no CPU fallback)")
@@ -63,6 +63,7 @@ class Engine:
         self.vae_cfg = dict(vae) if vae is not None else None
         self.hifigan_cfg = dict(hifigan) if hifigan is not None else None
         self.t5_cfg = dict(t5) if t5 is not None else None
+        self.vae_encoder = bool(vae_encoder) and vae is not None
         c = _lib.TangoConfig()
         c.dtype = _lib.DTYPES[dtype]
         c.latent_h, c.latent_w = 256, 16
@@ -93,6 +94,8 @@ class Engine:
             c.vae_embed_dim = v.get("embed_dim", 8)
             c.vae_out_ch = v["out_ch"]
             c.vae_scale_factor = v["scale_factor"]
+            c.vae_encoder = 1 if self.vae_encoder else 0
+            c.vae_in_channels = v.get("in_channels", 1)
         if self.hifigan_cfg is not None:
             h = self.hifigan_cfg
             c.voc_n_ups = len(h["upsample_rates"])
@@ -138,6 +141,8 @@ class Engine:
             out.update(W.unet_param_shapes(self.unet_cfg, "unet."))
         if self.vae_cfg is not None:
             out.update(W.vae_decoder_param_shapes(self.vae_cfg))
+            if self.vae_encoder:
+                out.update(W.vae_encoder_param_shapes(self.vae_cfg))
         if self.hifigan_cfg is not None:
             out.update(W.hifigan_param_shapes(self.hifigan_cfg))
         if self.t5_cfg is not None:
@@ -269,6 +274,20 @@ class Engine:
             _lib.check(self.lib.tango_engine_vae_decode(self._h, C.c_void_p(z.data_ptr()), C.c_void_p(mel.data_ptr()), B,
                                                         _stream_ptr()), "vae_decode")
         return mel
+
+    def vae_encode(self, mel):
+        """mel [B, 1, 4H, 4W] fp32 -> moments [B, 2*embed_dim, H, W] fp32 (= [mean | logvar]; autoencoder.py:52-58 up to quant_conv)"""
+        if not self.vae_encoder:
+            raise RuntimeError("Engine was created without vae_encoder=True")
+        x = self._f32(mel)
+        B = x.shape[0]
+        nl = len(self.vae_cfg["ch_mult"])
+        mom = torch.empty((B, 2 * self.vae_cfg.get("embed_dim", 8), x.shape[2] >> (nl - 1), x.shape[3] >> (nl - 1)),
+                          device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.tango_engine_vae_encode(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(mom.data_ptr()), B,
+                                                        _stream_ptr()), "vae_encode")
+        return mom
 
     def vocoder_samples(self, frames: int) -> int:
         return self.lib.tango_engine_vocoder_samples(self._h, frames)

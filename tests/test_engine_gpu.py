@@ -255,6 +255,37 @@ def test_vae_and_vocoder(dtype):
         assert snr >= 30.0
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_vae_encoder(dtype):
+    """AutoencoderKL.encode_first_stage / get_first_stage_encoding: full-size mel-VAE encoder (B = 2) on the
+    engine vs the oracle, and (fp32) vs the committed outputs of the reference itself (tests/golden/vae_enc_ref.npz)"""
+    import os
+    from tango_amd.autoencoder import AutoencoderKL, DiagonalGaussianDistribution
+    sd = W.synth_state_dict(W.vae_encoder_param_shapes(O.VAE_CONFIG), 4321)
+    vae = AutoencoderKL(ddconfig=dict(O.VAE_CONFIG, resolution=256, in_channels=1, double_z=True, attn_resolutions=[], dropout=0.0),
+                        embed_dim=8, scale_factor=O.VAE_CONFIG["scale_factor"], dtype=dtype, with_encoder=True)
+    vae.engine.load_synthetic(4321)
+    g = torch.Generator().manual_seed(43)
+    mel = torch.randn(2, 1, 1024, 64, generator=g) * 2.0 - 4.0
+    ref = O.vae_encode_moments(sd, O.VAE_CONFIG, mel)
+    post = vae.encode_first_stage(mel.cuda())
+    assert isinstance(post, DiagonalGaussianDistribution) and post.parameters.shape == (2, 16, 256, 16)
+    err = relerr(post.parameters.cpu(), ref)
+    print("vae encoder %s rel err %.3e" % (dtype, err))
+    assert err <= (1e-3 if dtype == "fp32" else 3e-2)
+    torch.manual_seed(5)
+    z = vae.get_first_stage_encoding(post)                 # draws randn(mean.shape) from the global CPU generator, like the reference
+    torch.manual_seed(5)
+    z_ref = O.vae_get_first_stage_encoding(ref, O.VAE_CONFIG, torch.randn(2, 8, 256, 16))
+    assert z.shape == (2, 8, 256, 16) and relerr(z.cpu(), z_ref) <= (1e-3 if dtype == "fp32" else 3e-2)
+    if dtype == "fp32":
+        gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vae_enc_ref.npz"))
+        m = gold["mom_slice"]
+        assert np.abs(post.parameters[:, :, ::17, ::3].cpu().numpy() - m).max() / np.abs(m).max() <= 1e-4
+        zz = gold["z_slice"]
+        assert np.abs(z[:, :, ::17, ::3].cpu().numpy() - zz).max() / np.abs(zz).max() <= 1e-4
+
+
 def test_generate_api_shapes():
     """Tango.generate_from_embeddings: tiny UNet + real VAE/vocoder, 2 prompts, 3 steps, device Philox noise."""
     from tango_amd.autoencoder import AutoencoderKL
