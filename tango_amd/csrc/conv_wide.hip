@@ -6,12 +6,12 @@
 // workgroup that covers 320 output channels stages each activation halo once for twice the work.  The level-0 convolutions
 // (N = 320) become single-column tilings: no second workgroup re-stages the same halo.
 //
-// Layout: 64-byte channel chunks (one MFMA k-step).  LDS = two halo buffers (chunk cc, cc+1; up to 480 halo pixels x 64 B
+// Layout: 64-byte channel chunks (one MFMA k-step).  LDS = two halo buffers (chunk cc, cc+1; up to 544 halo pixels x 64 B
 // each) + a FOUR-stage ring of weight items (320 rows x 64 B per (chunk, tap) item).  A DMA instruction covers 16 rows x 64 B;
 // the 16-byte piece of row h is XOR-swizzled on the source side with ((h >> 1) & 2): for 16 consecutive rows starting
 // ANYWHERE (the halo fragments start at an arbitrary pixel, shifted per tap) the four lane groups of a ds_read_b128 then
 // touch 16 distinct 16-byte bank slots.  Ping-pong at item granularity as in gemm_wide.hip:
-//   [ds_read 14 fragments | wait own DMAs of item i+1] barrier [issue halo piece (taps 0..3) + weight item i+3 | 40 MFMAs] barrier
+//   [ds_read 14 fragments | wait own DMAs of item i+1] barrier [issue halo piece (taps 0..4) + weight item i+3 | 40 MFMAs] barrier
 // with the two 4-wave halves one barrier out of phase.  Epilogue: wide_epilogue (bias, per-step bias, residual, out_scale).
 //
 // Reference op replaced: the ResnetBlock2D 3x3 convolutions and the up-/down-sampler convolutions of the UNet
@@ -24,8 +24,9 @@
 
 namespace tango {
 
-static constexpr int CW_HALO_MAX = 480;    // halo pixels per tile: 2 x 30 KiB halo + 80 KiB weight ring + 10 KiB source offsets = 150 KiB
-static constexpr int CW_NA = 4;            // halo DMA pieces (16 rows) per wave per channel chunk: 8 waves x 4 x 16 rows >= 480
+static constexpr int CW_HALO_MAX = 544;    // halo pixels per tile: 2 x 34 KiB halo + 80 KiB weight ring + 12 KiB source offsets = the whole 160-KiB LDS
+                                           // (544 = four 32 x 2 images with their borders: the UNet's level 3)
+static constexpr int CW_NA = 5;            // halo DMA pieces (16 rows) per wave per channel chunk: 8 waves x 5 x 16 rows >= 544
 
 template <typename T, bool RES, bool SK>
 __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, const unsigned char* zero_page, const int SR, const int nseg,

@@ -204,7 +204,8 @@ def test_conv3x3_repeat(lib, dtype, B, Cin, Cout, H, W, ups):
                                                 (256, 32, 320, 64, 4, 0),      # whole-image tiles (H * W = 256), one chunk
                                                 (32, 64, 640, 32, 8, 1),       # fused nearest x2 upsample, two column tiles
                                                 (28, 160, 640, 32, 32, 0),     # W = 32: 8-row tiles
-                                                (16, 512, 320, 64, 16, 0)])    # 64 tiles -> split-K x4 over the 16 channel chunks
+                                                (16, 512, 320, 64, 16, 0),     # 64 tiles -> split-K x4 over the 16 channel chunks
+                                                (64, 256, 1280, 32, 2, 0)])    # level 3: four 32 x 2 images per tile (halo 544), split-K x2
 def test_conv3x3_wide_repeat(lib, dtype, B, Cin, Cout, H, W, ups):
     """halo-reuse conv on the 256 x 320 tile (conv_wide.hip): >= 224 tiles, every tile geometry the UNet uses"""
     g = torch.Generator().manual_seed(Cin * Cout + H + W)
