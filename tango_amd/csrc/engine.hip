@@ -289,6 +289,7 @@ Engine::~Engine() {
     if (kv.second->slab) (void)hipFree(kv.second->slab);
   }
   for (auto& kv : vae_plans) if (kv.second->slab) (void)hipFree(kv.second->slab);
+  for (auto& kv : vae_enc_plans) if (kv.second->slab) (void)hipFree(kv.second->slab);
   for (auto& kv : voc_plans) if (kv.second->slab) (void)hipFree(kv.second->slab);
   for (auto& kv : t5_plans) if (kv.second->slab) (void)hipFree(kv.second->slab);
   for (void* p : owned) (void)hipFree(p);

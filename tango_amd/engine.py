@@ -268,6 +268,9 @@ class Engine:
         z = self._f32(latents)
         B = z.shape[0]
         nl = len(self.vae_cfg["ch_mult"])
+        want = (self.vae_cfg.get("embed_dim", 8), self._cfg.latent_h, self._cfg.latent_w)   # the plan's fixed input size
+        if z.dim() != 4 or tuple(z.shape[1:]) != want:
+            raise ValueError("vae_decode: latents must be [B, %d, %d, %d], got %s" % (want + (tuple(z.shape),)))
         mel = torch.empty((B, self.vae_cfg["out_ch"], z.shape[2] << (nl - 1), z.shape[3] << (nl - 1)),
                           device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
@@ -282,6 +285,12 @@ class Engine:
         x = self._f32(mel)
         B = x.shape[0]
         nl = len(self.vae_cfg["ch_mult"])
+        # the engine's encoder plan is built for ONE spatial size, (latent_h, latent_w) << (levels - 1) = 1024 x 64 mel bins
+        # (the C ABI sees a bare pointer and copies exactly that many bytes): refuse anything else instead of reading past
+        # `mel` / writing past `moments`.  The reference Encoder accepts any H, W; Tango only ever feeds this one.
+        want = (self.vae_cfg.get("in_channels", 1), self._cfg.latent_h << (nl - 1), self._cfg.latent_w << (nl - 1))
+        if x.dim() != 4 or tuple(x.shape[1:]) != want:
+            raise ValueError("vae_encode: mel must be [B, %d, %d, %d], got %s" % (want + (tuple(x.shape),)))
         mom = torch.empty((B, 2 * self.vae_cfg.get("embed_dim", 8), x.shape[2] >> (nl - 1), x.shape[3] >> (nl - 1)),
                           device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):

@@ -42,6 +42,12 @@ def build_pretrained_models(ckpt, vae_config=None, dtype="fp16", device="cuda:0"
     return vae, None
 
 
+def _hf_classes():
+    """(AutoTokenizer, T5EncoderModel) of models.py:98-100, imported on first use"""
+    from transformers import AutoTokenizer, T5EncoderModel
+    return AutoTokenizer, T5EncoderModel
+
+
 class _UNetHandle:
     """What callers read off `model.unet` (models.py:227)."""
 
@@ -124,10 +130,13 @@ class AudioDiffusion:
     def _ensure_text(self):
         if isinstance(self.text_encoder, str):
             raise RuntimeError("text_encoder='engine' is built by load_state_dict(); no checkpoint has been loaded yet")
-        if self.text_encoder is None or self.tokenizer is None:
-            from transformers import AutoTokenizer, T5EncoderModel   # models.py:98-100
-            self.tokenizer = AutoTokenizer.from_pretrained(self.text_encoder_name)
-            self.text_encoder = T5EncoderModel.from_pretrained(self.text_encoder_name).to(self.device).eval()
+        # each component is loaded only if IT is missing (models.py:98-100): an encoder that load_state_dict() already built
+        # from the checkpoint (text_encoder="engine") or that the caller supplied must never be replaced by stock hub
+        # weights just because no tokenizer was passed
+        if self.tokenizer is None:
+            self.tokenizer = _hf_classes()[0].from_pretrained(self.text_encoder_name)
+        if self.text_encoder is None:
+            self.text_encoder = _hf_classes()[1].from_pretrained(self.text_encoder_name).to(self.device).eval()
         self._apply_text_sd()
 
     def encode_text(self, prompt: List[str]):

@@ -6,6 +6,7 @@ used, otherwise small stand-ins with the same call surface, so the class can be 
 are expected under `<model_cache>/<name>/` (vae_config.json, main_config.json, pytorch_model_{vae,main}.bin -- the layout
 predict.py:73-86 reads); nothing is downloaded here.  The reference also loads an STFT module there; it is not on the
 generation path and is not built.  WAV files are written with the stdlib (batch_inference.write_wav)."""
+import copy
 import os
 from typing import Dict, Iterable, Optional
 
@@ -42,7 +43,11 @@ class Predictor(BasePredictor):
             if not os.path.isdir(path):
                 raise FileNotFoundError("model directory %s not found (the reference downloads %s here; there is no network)"
                                         % (path, "https://weights.replicate.delivery/default/declare-lab/tango.tar"))
-            self.models[k] = tango_cls(path, device=device, dtype=dtype, text_encoder=text_encoder, tokenizer=tokenizer)
+            # every model loads ITS checkpoint's text_encoder.* tensors into the encoder it is given: a shared module
+            # would end up with the last model's weights for all of them, so each model gets its own copy
+            # (the string "engine" builds a separate on-engine encoder per model anyway)
+            te = copy.deepcopy(text_encoder) if text_encoder is not None and not isinstance(text_encoder, str) else text_encoder
+            self.models[k] = tango_cls(path, device=device, dtype=dtype, text_encoder=te, tokenizer=tokenizer)
 
     def predict(self,
                 prompt: str = Input(description="Input prompt", default="Quiet speech and then and airplane flying away"),

@@ -96,7 +96,13 @@ class Tango:
             return pe.float(), pm
 
         def compute(pe, pm, offset, seed):
-            latents = self.model.inference_from_embeddings(pe, pm, self.scheduler, steps, guidance, seed=seed, sample_offset=offset)
+            # initial latents keyed by (broadcast seed, GLOBAL sample index), like the step noise: ranks that share a
+            # torch.manual_seed must not start their samples from identical noise, and the result must not depend on the
+            # number of ranks (parallel.py docstring)
+            b = pe.shape[0] // 2 if guidance > 1.0 else pe.shape[0]
+            lat = dp_initial_latents(seed, offset, b, self.model.unet.config.in_channels) * self.scheduler.init_noise_sigma
+            latents = self.model.inference_from_embeddings(pe, pm, self.scheduler, steps, guidance, latents=lat, seed=seed,
+                                                           sample_offset=offset)
             return self.vae.engine.vocode(self.vae.decode_first_stage(latents))      # int16 stays on the device
 
         with torch.no_grad():
@@ -109,6 +115,16 @@ class Tango:
             latents = self.model.inference_from_embeddings(prompt_embeds, boolean_prompt_mask, self.scheduler, steps, guidance, **kw)
             mel = self.vae.decode_first_stage(latents)
             return self.vae.decode_to_waveform(mel)
+
+
+def dp_initial_latents(seed, offset, count, channels=8):
+    """Initial latents [count, channels, 256, 16] (fp32, CPU) of the samples with GLOBAL indices offset .. offset+count-1 under
+    the pass seed: one torch generator per sample, so a shard of a batch draws exactly what the unsharded batch would."""
+    out = []
+    for i in range(count):
+        g = torch.Generator(device="cpu").manual_seed((int(seed) * 1000003 + offset + i) % (2 ** 63 - 1))
+        out.append(torch.randn(channels, 256, 16, generator=g))
+    return torch.stack(out) if out else torch.zeros(0, channels, 256, 16)
 
 
 def _ddpm_keys(cfg):

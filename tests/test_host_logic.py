@@ -223,3 +223,68 @@ def test_swizzle64_conflict_free():
     (tools/check_swizzle64.py asserts it exhaustively)"""
     import runpy
     runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_swizzle64.py"))
+
+
+def test_dp_initial_latents_are_shard_invariant():
+    """the DP entry point draws each sample's initial latents from (pass seed, GLOBAL sample index) -- a
+    shard reproduces its slice of the unsharded draw, samples differ from each other and from another seed's."""
+    from tango_amd.tango import dp_initial_latents
+    full = dp_initial_latents(4242, 0, 5)
+    parts = torch.cat([dp_initial_latents(4242, 0, 2), dp_initial_latents(4242, 2, 3)])
+    assert full.shape == (5, 8, 256, 16) and torch.equal(full, parts)
+    assert not torch.equal(full[0], full[1]) and not torch.equal(full, dp_initial_latents(4243, 0, 5))
+    assert abs(full.std().item() - 1.0) < 0.02 and dp_initial_latents(1, 0, 0).shape == (0, 8, 256, 16)
+
+
+def test_ensure_text_loads_only_the_missing_component(monkeypatch):
+    """with an encoder already present (user-supplied, or built from the checkpoint by text_encoder='engine')
+    and no tokenizer, _ensure_text() must fetch ONLY the tokenizer -- never replace the encoder with stock hub weights."""
+    from tango_amd import models as M
+    from tango_amd.models import AudioDiffusion
+
+    loaded = []
+
+    class Tok:
+        @staticmethod
+        def from_pretrained(name):
+            loaded.append(("tok", name))
+            return "tokenizer"
+
+    class Enc:
+        @staticmethod
+        def from_pretrained(name):
+            loaded.append(("enc", name))
+            raise AssertionError("the encoder must not be reloaded")
+
+    monkeypatch.setattr(M, "_hf_classes", lambda: (Tok, Enc))
+    m = AudioDiffusion.__new__(AudioDiffusion)          # no engine: only the text plumbing is exercised
+    mine = object()
+    m.text_encoder, m.tokenizer, m.text_encoder_name, m._text_sd, m.device = mine, None, "google/flan-t5-large", None, "cpu"
+    m._ensure_text()
+    assert m.text_encoder is mine and m.tokenizer == "tokenizer" and loaded == [("tok", "google/flan-t5-large")]
+    m.text_encoder = "engine"                            # not built yet: a clear error, no hub access
+    with pytest.raises(RuntimeError):
+        m._ensure_text()
+
+
+def test_predictor_gives_each_model_its_own_text_encoder(tmp_path):
+    """every Tango loads its checkpoint's text_encoder.* into the module it receives -- a shared module would
+    keep only the last model's weights."""
+    import torch.nn as nn
+
+    from tango_amd.predict import Predictor
+
+    got = []
+
+    class FakeTango:
+        def __init__(self, path, device="cuda:0", dtype="fp16", text_encoder=None, tokenizer=None):
+            got.append(text_encoder)
+
+    for k in ("tango2", "tango2-full"):
+        (tmp_path / k).mkdir()
+    enc = nn.Linear(2, 2)
+    Predictor().setup(model_cache=str(tmp_path), tango_cls=FakeTango, text_encoder=enc)
+    assert len(got) == 2 and got[0] is not got[1] and got[0] is not enc and torch.equal(got[0].weight, enc.weight)
+    got.clear()
+    Predictor().setup(model_cache=str(tmp_path), tango_cls=FakeTango, text_encoder="engine")
+    assert got == ["engine", "engine"]

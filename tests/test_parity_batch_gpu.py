@@ -1,0 +1,145 @@
+"""Parity AT THE BENCHMARKED BATCH, through the C ABI.
+
+Every other full-size test runs the UNet at batch 2 (one CFG pair).  There level 0 is 32 tiles and dispatch takes the
+split-K variants; BASELINE config 3 (B = 32 prompts, UNet batch 64) and B = 8 take other kernels: the one-shot 256 x 320
+`conv3x3_wide` / `gemm_wide` paths, the B2 = 64 arena / concat plan, 1.3-GB GEGLU outputs.  This file runs exactly those
+plans -- Engine(UNET_CONFIG_LARGE), L = 64, the uncond rows masked down to token 0 as T5("") is (models.py:282-289) --
+
+  (i)  one `unet_forward` at UNet batch 2B,
+  (ii) a 3-step CFG DDPM loop with injected noise through the captured hipGraph (models.py:233-249),
+
+on the fp32 and fp16 engines at B = 32 and B = 8 and compares rows with the fp32 CPU oracle.  Samples are independent
+(no cross-sample op anywhere), so the oracle is run at B = 1 on the rows {0, 15, 31} (B = 32) and {0, 3, 7}
+(B = 8) only: prompt i's CFG pair is rows (i, B + i) of the engine batch.  The B = 8 inputs are the first 8 prompts of the
+B = 32 inputs, so the oracle rows are shared.  Tolerances are those of test_config1_* / test_unet_forward_large.
+
+Plus the op case nothing else reaches: the level-0 GEGLU projection at config-3 size, M = 262144, N = 2560, K = 320 with
+the folded LayerNorm (attention.py:412-433), against F.linear on sampled rows."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tango_oracle as O  # noqa: E402  (checker only)
+from tango_amd import weights as W  # noqa: E402
+from tango_amd.engine import Engine  # noqa: E402
+from tango_amd.scheduler import SD21_SCHEDULER_CONFIG, DDPMScheduler  # noqa: E402
+
+_KEYS = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "prediction_type", "clip_sample", "variance_type")
+BMAX, L, NSTEP, TFWD = 32, 64, 3, 500
+ROWS = {32: (0, 15, 31), 8: (0, 3, 7)}
+_cache = {}
+
+
+def _inputs():
+    """seeded inputs for 32 prompts; a B-prompt run uses prompts [0, B)"""
+    if "in" not in _cache:
+        g = torch.Generator().manual_seed(3232)
+        cond = torch.randn(BMAX, L, 1024, generator=g)
+        unc = torch.randn(BMAX, L, 1024, generator=g)
+        mask_c = torch.ones(BMAX, L, dtype=torch.bool)
+        mask_c[1::3, 40:] = False                        # ragged cond prompts too (padding of shorter prompts in a batch)
+        mask_u = torch.zeros(BMAX, L, dtype=torch.bool)
+        mask_u[:, 0] = True
+        lat0 = torch.randn(BMAX, 8, 256, 16, generator=g)
+        noises = torch.randn(NSTEP, BMAX, 8, 256, 16, generator=g)
+        x2 = torch.randn(2 * BMAX, 8, 256, 16, generator=g)     # unet_forward test: independent sample per row of the UNet batch
+        _cache["in"] = dict(cond=cond, unc=unc, mask_c=mask_c, mask_u=mask_u, lat0=lat0, noises=noises, x2=x2)
+    return _cache["in"]
+
+
+def _sd():
+    if "sd" not in _cache:
+        _cache["sd"] = W.synth_state_dict(W.unet_param_shapes(O.UNET_CONFIG_LARGE, "unet."), 1234)
+    return _cache["sd"]
+
+
+def oracle_row(i):
+    """fp32 CPU oracle for prompt i alone (B = 1): the UNet forward of its CFG pair and the 3-step loop"""
+    key = ("row", i)
+    if key not in _cache:
+        d = _inputs()
+        enc = torch.stack([d["unc"][i], d["cond"][i]])
+        mask = torch.stack([d["mask_u"][i], d["mask_c"][i]])
+        with torch.no_grad():
+            # forward: rows (i, BMAX + i) of x2 -- the B = 8 run uses rows (i, 8 + i) of ITS batch, built from the same tensors
+            x = torch.stack([d["x2"][i], d["x2"][BMAX + i]])
+            fwd = O.unet_forward(_sd(), O.UNET_CONFIG_LARGE, x, TFWD, enc, mask, prefix="unet.")
+            lat = O.denoise_loop(_sd(), O.UNET_CONFIG_LARGE, O.DDPMOracle(**O.SD21_SCHEDULER), enc, mask, d["lat0"][i:i + 1].clone(),
+                                 NSTEP, 3.0, noises=[n[i:i + 1] for n in d["noises"]], prefix="unet.")
+        _cache[key] = (fwd, lat[0])
+    return _cache[key]
+
+
+def _engine(dtype):
+    e = Engine(unet=O.UNET_CONFIG_LARGE, dtype=dtype)
+    e.load_synthetic(1234)
+    return e
+
+
+def _batch(B):
+    d = _inputs()
+    enc = torch.cat([d["unc"][:B], d["cond"][:B]])
+    mask = torch.cat([d["mask_u"][:B], d["mask_c"][:B]])
+    x2 = torch.cat([d["x2"][:B], d["x2"][BMAX:BMAX + B]])
+    return enc, mask, x2, d["lat0"][:B].clone(), d["noises"][:, :B].contiguous()
+
+
+@pytest.mark.parametrize("dtype,fwd_tol,lat_tol", [("fp32", 1e-3, 1e-2), ("fp16", 3e-2, 2e-2)])
+def test_unet_and_loop_at_benchmarked_batch(dtype, fwd_tol, lat_tol):
+    e = _engine(dtype)
+    sch = DDPMScheduler.from_config({k: SD21_SCHEDULER_CONFIG[k] for k in _KEYS})
+    sch.set_timesteps(NSTEP)
+    for B in (32, 8):
+        enc, mask, x2, lat0, noises = _batch(B)
+        out = e.unet_forward(x2.cuda(), TFWD, enc.cuda(), mask.cuda()).cpu()
+        lat = lat0.cuda()
+        e.denoise(lat, enc.cuda(), mask.cuda(), sch.timesteps.numpy(), sch.coef_table(), 3.0, noise=noises.cuda(), use_graph=True)
+        torch.cuda.synchronize()
+        lat = lat.cpu()
+        assert torch.isfinite(out).all() and torch.isfinite(lat).all()
+        for i in ROWS[B]:
+            fwd_ref, lat_ref = oracle_row(i)
+            got = torch.stack([out[i], out[B + i]])
+            ferr = ((got - fwd_ref).abs().max() / fwd_ref.abs().max()).item()
+            lerr = (lat[i] - lat_ref).abs().max().item()
+            print("B=%d (UNet batch %d) %s engine, prompt %d: unet_forward rel err %.3e, %d-step CFG loop (hipGraph) latents max abs err %.3e (|ref| max %.2f)"
+                  % (B, 2 * B, dtype, i, ferr, NSTEP, lerr, lat_ref.abs().max()))
+            assert ferr <= fwd_tol, (B, i, ferr)
+            assert lerr <= lat_tol, (B, i, lerr)
+        # the rows NOT compared with the oracle must at least be distinct trajectories of the right scale
+        assert not torch.equal(lat[1], lat[2]) and 0.3 < lat.std().item() < 3.0
+    del e
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_geglu_projection_config3_size(lib, dtype):
+    """M = 262144 (64 x 4096 tokens), N = 2560 (GEGLU of 8C = 2560 -> 1280 outputs), K = 320, folded LayerNorm: the level-0
+    ff.net.0 launch of config 3, 1.3 GB of operands.  Checked on 4096 sampled rows in fp64."""
+    DT = {"fp16": (1, torch.float16, 4e-3), "bf16": (2, torch.bfloat16, 3e-2)}
+    code, tdt, tol = DT[dtype]
+    M, Cc, K = 262144, 1280, 320
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = (torch.randn(M, K, device="cuda", generator=g) * 1.5 + 0.4).to(tdt).float()
+    w = (torch.randn(2 * Cc, K, device="cuda", generator=g) / K ** 0.5).to(tdt).float()
+    b = torch.randn(2 * Cc, device="cuda", generator=g) * 0.1
+    gam = 1.0 + 0.2 * torch.randn(K, device="cuda", generator=g)
+    bet = 0.1 * torch.randn(K, device="cuda", generator=g)
+    out = torch.empty(M, Cc, device="cuda")
+    rc = lib.tango_op_linear_ln(code, C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()),
+                                C.c_void_p(gam.data_ptr()), C.c_void_p(bet.data_ptr()), None, C.c_void_p(out.data_ptr()),
+                                M, 2 * Cc, K, 1, 1e-5, None)
+    assert rc == 0, lib.tango_last_error().decode()
+    torch.cuda.synchronize()
+    idx = torch.randint(0, M, (4096,), device="cuda", generator=g)
+    idx[:4] = torch.tensor([0, 255, M - 256, M - 1], device="cuda")          # first / last tile edges
+    xs = x[idx].double()
+    y = F.linear(F.layer_norm(xs, (K,), gam.double(), bet.double(), 1e-5), w.double(), b.double())
+    ref = y[:, :Cc] * F.gelu(y[:, Cc:])
+    err = ((out[idx].double() - ref).abs().max() / ref.abs().max()).item()
+    print("GEGLU projection M=262144 N=2560 K=320 %s: rel err %.3e on 4096 sampled rows" % (dtype, err))
+    assert err <= tol
+    assert torch.isfinite(out).all()
