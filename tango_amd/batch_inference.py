@@ -97,13 +97,16 @@ def parse_args(argv: Optional[Iterable[str]] = None):
     ap.add_argument("--device", type=str, default="cuda:0")
     ap.add_argument("--dtype", type=str, default="fp16", choices=["fp32", "fp16", "bf16"])
     ap.add_argument("--out_root", type=str, default="outputs")
+    ap.add_argument("--text_encoder", type=str, default="torch", choices=["torch", "engine"],
+                    help="torch: transformers T5EncoderModel under PyTorch-ROCm (the reference's module); engine: the checkpoint's "
+                         "FLAN-T5 tensors on the HIP engine (tango_engine_encode_text)")
     return ap.parse_args(argv)
 
 
 def main(argv: Optional[Iterable[str]] = None) -> dict:
     args = parse_args(argv)
     from .tango import Tango          # needs the HIP library and a GPU: fails loudly otherwise
-    tango = Tango(args.model, device=args.device, dtype=args.dtype)
+    tango = Tango(args.model, device=args.device, dtype=args.dtype, text_encoder="engine" if args.text_encoder == "engine" else None)
     prompts = read_prompts(args.test_file, args.text_key, args.prefix)
     rec = generate_and_save(tango, prompts, args.num_steps, args.guidance, args.batch_size, args.num_samples, args.out_root,
                             tag="_".join(p for p in args.model.strip("/").split("/")[-2:] if p))

@@ -184,14 +184,11 @@ struct GemmParams {
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s);
 bool conv_halo_ok(int dtype, const GemmParams& p);
 int launch_conv_halo(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s);
-bool gemm_pers_ok(int dtype, const GemmParams& p);   // persistent LDS-DMA GEMM for the big linears (gemm_pers.hip)
-int launch_gemm_pers(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s);
 bool gemm_wide_ok(int dtype, const GemmParams& p);   // 256 x 320 ping-pong LDS-DMA GEMM for the big 16-bit linears (gemm_wide.hip)
 int launch_gemm_wide(int dtype, const GemmParams& p, hipStream_t s);
 bool conv_wide_ok(int dtype, const GemmParams& p);   // 3x3 halo-reuse conv on the 256 x 320 tile (conv_wide.hip)
 int launch_conv_wide(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s);
 int conv_wide_pick_splitk(int dtype, const GemmParams& p);
-int gemm_wide_pick_splitk(int dtype, const GemmParams& p);
 int launch_splitk_reduce(int dtype, const GemmParams& p, hipStream_t s);   // gemm.hip: sums ws [splits][M][N] and applies the epilogue
 bool gemm_dma_ok(int dtype, const GemmParams& p);
 int launch_gemm_dma(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s);

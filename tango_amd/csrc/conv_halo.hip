@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "tuning.h"
 #include "gemm_device.h"
 
 namespace tango {
@@ -312,8 +313,7 @@ static bool halo_geom(const GemmParams& p, HaloGeom& g) {
 }
 
 bool conv_halo_ok(int dtype, const GemmParams& p) {
-  static const bool off = getenv("TANGO_NO_HALO_CONV") != nullptr;      // experiment switch
-  if (off) return false;
+  if (tuning().no_halo_conv) return false;
   const int esz = dtype == DT_F32 ? 4 : 2;
   if (p.mode != GATHER_2D || p.stride != 1 || p.pad != 1 || p.ups < 0 || p.ups > 1 || (p.Hin << p.ups) != p.H || (p.Win << p.ups) != p.Wd) return false;
   if (p.batch != 1 || p.splitk > 1 || p.a_act != ACT_NONE || p.epi == EPI_GEGLU || p.epi == EPI_VT) return false;
@@ -322,9 +322,8 @@ bool conv_halo_ok(int dtype, const GemmParams& p) {
   if (p.N % bn != 0) return false;
   HaloGeom g;
   if (!halo_geom(p, g)) return false;
-  static const bool force = getenv("TANGO_FORCE_DMA_GEMM") != nullptr;  // tests: exercise this kernel on small shapes
   const long tiles = (long)(p.M / 256) * (p.N / bn);
-  return force || tiles >= 256;
+  return tuning().force_big_kernels || tiles >= 256;
 }
 
 template <typename T, int BN>
@@ -333,22 +332,18 @@ static int launch_halo_cfg(const GemmParams& p, const unsigned char* zero_page, 
   if (!halo_geom(p, g)) TANGO_FAIL("conv_halo: unsupported geometry");
   const int abytes = ((g.halo + 7) / 8) * 1024;
   const int lds = 2 * abytes + 3 * BN * 128;
-  static const int abl = getenv("TANGO_HALO_ABL") ? atoi(getenv("TANGO_HALO_ABL")) : 0;   // ablation study switch
-  // ping-pong loop: measured equal to the lock-step loop on the UNet convs (round 2: 3.81 vs 3.71 ms on the level-0 convs;
-  // the two waves of a SIMD already self-stagger inside an item, the 3 extra barriers per item buy nothing) -> opt-in
-  const char* ppe = getenv("TANGO_CONV_PP");
-  const bool pp = ppe && ppe[0] == '1';
-  const int variant = abl ? 0 : (pp ? 2 : 1);
-  auto kfn = abl ? conv3x3_halo_kernel<T, BN, true, false> : (pp ? conv3x3_halo_kernel<T, BN, false, true> : conv3x3_halo_kernel<T, BN, false, false>);
-  static int attr_lds[3] = {0, 0, 0};
-  if (lds > attr_lds[variant]) {
+  // Only the product instantiation is compiled: lock-step main loop, no ablation hooks.  (The ping-pong variant measured
+  // equal on the UNet convs -- 3.81 vs 3.71 ms on the level-0 convs, profiles/r2_unet_ops_pp_vs_lockstep.txt -- and the
+  // ablation hooks are a tools/ build: tools/halo_ablation.sh documents how the round-1 table was taken.)
+  auto kfn = conv3x3_halo_kernel<T, BN, false, false>;
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
     TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_lds[variant] = lds;
+    attr_lds = lds;
   }
   const int tiles = (p.M / 256) * (p.N / BN);
-  static const bool no_stage = getenv("TANGO_NO_STAGED_EPILOGUE") != nullptr;   // experiment switch
-  const int staged = (!no_stage && epilogue_can_stage<T>(p)) ? 1 : 0;
-  static const int pp_mode = getenv("TANGO_PP_HALF") ? atoi(getenv("TANGO_PP_HALF")) : 0;   // 0: waves w, w + 4 (one workgroup per CU: they share a SIMD, tools/simd_probe); 1: read HW_ID (+1 us per tile)
+  const int staged = epilogue_can_stage<T>(p) ? 1 : 0;
+  const int abl = 0, pp_mode = 0;
   hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(512), lds, s, p, zero_page, g.SR, g.nseg, abytes, abl, staged, pp_mode);
   TANGO_HIP(hipGetLastError());
   return 0;

@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "tuning.h"
 #include "gemm_device.h"
 #include "gemm_wide_device.h"
 
@@ -241,8 +242,7 @@ static bool wide_halo_geom(const GemmParams& p, WideHaloGeom& g) {
 }
 
 bool conv_wide_ok(int dtype, const GemmParams& p) {
-  static const bool off = getenv("TANGO_NO_WIDE_CONV") != nullptr;      // experiment switch
-  if (off || dtype == DT_F32) return false;
+  if (tuning().no_wide_conv || dtype == DT_F32) return false;
   if (p.mode != GATHER_2D || p.stride != 1 || p.pad != 1 || p.ups < 0 || p.ups > 1 || (p.Hin << p.ups) != p.H || (p.Win << p.ups) != p.Wd) return false;
   if (p.batch != 1 || p.a_act != ACT_NONE || p.epi != EPI_NONE || p.bias_rows) return false;
   if (p.splitk > 1 ? (!p.ws || p.splitk > p.Cin / 32 || p.N % 4 != 0) : (p.e_act != ACT_NONE || p.out_f32)) return false;
@@ -254,17 +254,15 @@ bool conv_wide_ok(int dtype, const GemmParams& p) {
   if ((int64_t)(p.M >> (2 * p.ups)) * p.lda * 2 >= (int64_t)0xFFFF0000 || (int64_t)320 * p.Kp * 2 >= (int64_t)0xFFFF0000) return false;
   WideHaloGeom g;
   if (!wide_halo_geom(p, g)) return false;
-  static const bool force = getenv("TANGO_FORCE_DMA_GEMM") != nullptr;  // tests: exercise this kernel on small shapes
   const long tiles = (long)(p.M / 256) * (p.N / 320) * (p.splitk > 1 ? p.splitk : 1);
-  return force || tiles >= 224;
+  return tuning().force_big_kernels || tiles >= 224;
 }
 
 // split-K factor the wide conv wants for a problem whose 256 x 320 tiling does not fill the chip (0: not a wide-conv problem)
 int conv_wide_pick_splitk(int dtype, const GemmParams& p) {
   GemmParams q = p;
   q.splitk = 1;
-  static const bool force = getenv("TANGO_FORCE_DMA_GEMM") != nullptr;
-  if (force || p.mode != GATHER_2D || dtype == DT_F32 || p.M % 256 != 0 || p.N % 320 != 0 || p.Cin % 32 != 0) return 0;
+  if (tuning().force_big_kernels || p.mode != GATHER_2D || dtype == DT_F32 || p.M % 256 != 0 || p.N % 320 != 0 || p.Cin % 32 != 0) return 0;
   const long tiles = (long)(p.M / 256) * (p.N / 320);
   // measured (B = 8 / 16 UNet steps, profiles/r2_unet_ops_small_batch_splitk.txt): 64 tiles x 4 splits beat the 4-wave tiles'
   // split-K by 21-27 %; 128 tiles x 2 splits LOSE to the unsplit 256 x 160 halo kernel by 14-20 %

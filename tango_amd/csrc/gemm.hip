@@ -296,8 +296,7 @@ static int launch_t(const GemmParams& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return 0;
   if (p.K % p.Cin != 0) TANGO_FAIL("gemm: K must be taps*Cin");
   if ((p.lda * (int64_t)sizeof(T)) % 16 != 0 || (p.Kp * (int64_t)sizeof(T)) % 16 != 0) TANGO_FAIL("gemm: lda/Kp must be 16-byte multiples");
-  static const bool force64 = getenv("TANGO_GEMM_BKB64") != nullptr;   // experiment switch
-  if (cb % 128 == 0 && !force64) return launch_mode<T, 128>(p, s);
+  if (cb % 128 == 0) return launch_mode<T, 128>(p, s);
   if (cb % 64 == 0) return launch_mode<T, 64>(p, s);
   TANGO_FAIL("gemm: Cin*sizeof(T) must be a multiple of 64 bytes");
 }
@@ -320,13 +319,10 @@ int gemm_pick_splitk(int dtype, const GemmParams& p) {
   if (p.mode == GATHER_1D && !(p.taps == 1 && p.rows_pb == p.M && p.in_mul == 1 && p.in_off == 0 && p.out_mul == 1 && p.out_off == 0))
     return 1;
   if (linear_stream_ok(dtype, p)) return 1;
-  static const bool wide_sk = getenv("TANGO_NO_WIDE_SPLITK") == nullptr;          // experiment switch
-  if (wide_sk) {
-    int sw = conv_wide_pick_splitk(dtype, p);          // e.g. 64 tiles of 256 x 320 -> 4 splits = one workgroup per CU
-    // linears: measured at M = 4096 (64 tiles x 4 splits) the wide kernel is no faster than the 4-wave tiles' split-K
-    // (0.250 vs 0.212 ms for N = K = 1280 x5): opt-in
-    static const bool wide_sk_lin = getenv("TANGO_WIDE_SPLITK_LINEAR") != nullptr;
-    if (sw <= 1 && wide_sk_lin) sw = gemm_wide_pick_splitk(dtype, p);
+  {
+    const int sw = conv_wide_pick_splitk(dtype, p);    // e.g. 64 tiles of 256 x 320 -> 4 splits = one workgroup per CU
+    // (linears: measured at M = 4096 -- 64 tiles x 4 splits -- the wide kernel is no faster than the 4-wave tiles' split-K,
+    //  0.250 vs 0.212 ms for N = K = 1280 x5, so gemm_wide_pick_splitk() is not consulted here)
     if (sw > 1) return sw;
   }
   const int esz = dtype == DT_F32 ? 4 : 2;
@@ -337,8 +333,7 @@ int gemm_pick_splitk(int dtype, const GemmParams& p) {
   const int tiles = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
   if (tiles >= 400) return 1;
   int s = (512 + tiles / 2) / tiles;   // aim for ~2 workgroups per CU
-  static const int minch = getenv("TANGO_SPLITK_MINCHUNKS") ? atoi(getenv("TANGO_SPLITK_MINCHUNKS")) : 3;
-  if (s > nk / minch) s = nk / minch;     // keep >= minch k-chunks per split
+  if (s > nk / 3) s = nk / 3;             // keep >= 3 k-chunks per split (measured sweep, round 1 v15)
   if (s > 32) s = 32;
   return s < 2 ? 1 : s;
 }
@@ -348,15 +343,12 @@ int launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
   // (measured, same box: M=65536 N=640 K=640 x20 2.38 -> 1.87 ms; K=320 rows: no difference, stay on the streaming kernel)
   // ... and short rows the streaming kernel has no instantiation for (conv_in as im2col + linear, K = 96: 207 -> ~50 us)
   if (!p.ln_fold && (p.K >= 640 || p.epi == EPI_VT || !linear_stream_ok(dtype, p)) && gemm_wide_ok(dtype, p)) return launch_gemm_wide(dtype, p, s);
-  if (p.splitk > 1 && p.mode == GATHER_1D && gemm_wide_ok(dtype, p)) return launch_gemm_wide(dtype, p, s);
-  static const bool wide_ln = !(getenv("TANGO_WIDE_LN") && getenv("TANGO_WIDE_LN")[0] == '0');   // experiment switch
-  if (p.ln_fold && (wide_ln || !linear_stream_ok(dtype, p)) && gemm_wide_ok(dtype, p)) return launch_gemm_wide(dtype, p, s);
+  if (p.ln_fold && gemm_wide_ok(dtype, p)) return launch_gemm_wide(dtype, p, s);
   if (linear_stream_ok(dtype, p)) return launch_linear_stream(dtype, p, s);
   if (p.ln_fold) TANGO_FAIL("gemm: ln_fold is only implemented by the streaming linear kernel");
   if (conv_wide_ok(dtype, p)) return launch_conv_wide(dtype, p, g_zero_page, s);
   if (conv_halo_ok(dtype, p)) return launch_conv_halo(dtype, p, g_zero_page, s);
   if (gemm_wide_ok(dtype, p)) return launch_gemm_wide(dtype, p, s);
-  if (gemm_pers_ok(dtype, p)) return launch_gemm_pers(dtype, p, g_zero_page, s);
   if (gemm_dma_ok(dtype, p)) return launch_gemm_dma(dtype, p, g_zero_page, s);
   switch (dtype) {
     case DT_F32: return launch_t<float>(p, s);

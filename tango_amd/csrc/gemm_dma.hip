@@ -3,6 +3,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "tuning.h"
 #include "gemm_device.h"
 
 namespace tango {
@@ -213,18 +214,15 @@ static const unsigned char* g_zero_page = nullptr;
 template <typename T, int BN, int MODE>
 static int launch_dma_cfg(const GemmParams& p, hipStream_t s) {
   constexpr int LDS = 3 * (256 + BN) * 128;
-  const char* ppe = getenv("TANGO_GEMM_PP");                                              // experiment switch: 0 = lock-step loop
-  const bool pp = !(ppe && ppe[0] == '0');
-  auto kfn = pp ? gemm_dma_kernel<T, BN, MODE, true> : gemm_dma_kernel<T, BN, MODE, false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[pp]) {
+  auto kfn = gemm_dma_kernel<T, BN, MODE, true>;     // ping-pong main loop (the lock-step variant is no longer compiled)
+  static bool attr_set = false;
+  if (!attr_set) {
     TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set[pp] = true;
+    attr_set = true;
   }
   const int MT = (p.M + 255) / 256, NT = (p.N + BN - 1) / BN;
-  static const bool no_stage = getenv("TANGO_NO_STAGED_EPILOGUE") != nullptr;   // experiment switch
-  const int staged = (!no_stage && MODE != MODE_CONV1D && epilogue_can_stage<T>(p)) ? 1 : 0;
-  static const int pp_mode = getenv("TANGO_PP_HALF") ? atoi(getenv("TANGO_PP_HALF")) : 0;   // 0: waves w, w + 4 (one workgroup per CU: they share a SIMD, tools/simd_probe); 1: read HW_ID (+1 us per tile)
+  const int staged = (MODE != MODE_CONV1D && epilogue_can_stage<T>(p)) ? 1 : 0;
+  const int pp_mode = 0;   // static half assignment: waves w and w + 4 share a SIMD (tools/simd_probe.hip)
   hipLaunchKernelGGL(kfn, dim3((unsigned)(MT * NT)), dim3(512), LDS, s, p, (const unsigned char*)g_zero_page, staged, pp_mode);
   TANGO_HIP(hipGetLastError());
   return 0;
@@ -232,16 +230,14 @@ static int launch_dma_cfg(const GemmParams& p, hipStream_t s) {
 
 // the wide LDS-DMA kernel takes the big problems: enough 256-row tiles to fill the chip, 128-byte k-chunks
 bool gemm_dma_ok(int dtype, const GemmParams& p) {
-  static const bool off = getenv("TANGO_NO_DMA_GEMM") != nullptr;
-  if (off) return false;
+  if (tuning().no_dma_gemm) return false;
   const int esz = dtype == DT_F32 ? 4 : 2;
   if (p.batch != 1 || p.splitk > 1 || p.a_act != ACT_NONE || (p.Cin * esz) % 128 != 0) return false;
   const int bn = (p.epi == EPI_GEGLU || p.N % 160 != 0) ? 128 : 160;
   if (p.N % bn != 0) return false;
   if (p.K / (128 / esz) < 4) return false;
-  static const bool force = getenv("TANGO_FORCE_DMA_GEMM") != nullptr;   // tests: exercise this kernel on small shapes
   const long tiles = (long)((p.M + 255) / 256) * (p.N / bn);
-  return force || tiles >= 448;
+  return tuning().force_big_kernels || tiles >= 448;
 }
 
 template <typename T>

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "common.h"
+#include "tuning.h"
 #include "gemm_device.h"
 #include "gemm_wide_device.h"
 
@@ -62,8 +63,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // NST stages
 
   // TANGO_WIDE_TRACE=1: wave 0 of every workgroup records 100 MHz timestamps at start / first chunk landed / loop end / end
+#ifdef TANGO_WIDE_TRACE_BUILD      // diagnostic build only (profiles/r2_wide_trace*.txt): per-workgroup phase times
   unsigned long long t_start = 0, t_first = 0, t_loop = 0;
   if (trace) t_start = __builtin_amdgcn_s_memrealtime();
+#endif
   const int NT = p.N / BN;
   int bid = blockIdx.x;
   {
@@ -135,7 +138,9 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
   const int half = pp_phase_half(wave, lane, (unsigned*)(dsm + (NST - 1) * STAGE), pp_mode);   // scratch: last stage, first DMA'd in the loop
   wait_inflight(npro - 1);                              // chunk 0 landed
   pp_barrier();
+#ifdef TANGO_WIDE_TRACE_BUILD
   if (trace) t_first = __builtin_amdgcn_s_memrealtime();
+#endif
   if (half) pp_barrier();                               // the stagger
   int st = 0;
   for (int kc = 0; kc < nk; ++kc) {
@@ -167,7 +172,9 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
   }
   if (!half) pp_barrier();
   __syncthreads();   // every wave is past its last fragment read: the operand stages become the staging area
+#ifdef TANGO_WIDE_TRACE_BUILD
   if (trace) t_loop = __builtin_amdgcn_s_memrealtime();
+#endif
   float mean[TM] = {0.f, 0.f, 0.f, 0.f}, rstd[TM] = {1.f, 1.f, 1.f, 1.f};
   if (LN) {
 #pragma unroll
@@ -188,54 +195,39 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
   }
   if (VT && n0 >= p.vt_n0) wide_epilogue_vt<T, LN>(p, acc, mean, rstd, m0 + wm * TM * 16, n0 + wn * TN * 16, lane, slice);
   else wide_epilogue<T, GEGLU, RES, LN>(p, acc, mean, rstd, m0 + wm * TM * 16, n0 + wn * TN * 16, lane, slice);
+#ifdef TANGO_WIDE_TRACE_BUILD
   if (trace && tid == 0) {
     const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();      // every store of wave 0 issued ...
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // ... and acknowledged
     unsigned long long* t = trace + (size_t)blockIdx.x * 5;
     t[0] = t_start; t[1] = t_first; t[2] = t_loop; t[3] = t_issued; t[4] = __builtin_amdgcn_s_memrealtime();
   }
+#endif
 }
 
 // which problems: 16-bit linear, plain / GEGLU epilogue into T, whole 256 x 320 tiles, at least NST k-chunks, and enough
 // tiles to fill the chip
 bool gemm_wide_ok(int dtype, const GemmParams& p) {
-  static const bool off = getenv("TANGO_NO_WIDE_GEMM") != nullptr;
-  if (off || dtype == DT_F32) return false;
+  if (tuning().no_wide_gemm || dtype == DT_F32) return false;
   const bool linear = p.mode == GATHER_1D && p.taps == 1 && p.rows_pb == p.M && p.in_mul == 1 && p.in_off == 0 && p.out_mul == 1 &&
                       p.out_off == 0 && p.Lin >= p.M;
   if (!linear || p.batch != 1 || p.a_act != ACT_NONE || p.bias_rows) return false;
-  if (p.splitk > 1 ? (!p.ws || p.epi != EPI_NONE || p.ln_fold || p.N % 4 != 0 || p.splitk * 4 > p.K / 32) : p.out_f32) return false;
+  // (split-K on this tile was measured in round 2 -- no gain over the 4-wave tiles' split-K at M = 4096 -- and is not compiled)
+  if (p.splitk > 1 || p.out_f32) return false;
   if (p.ln_fold && (!p.wsum || ((uintptr_t)p.wsum & 15) || p.alpha != 1.f)) return false;
   if (p.epi != EPI_NONE && p.epi != EPI_GEGLU && p.epi != EPI_VT) return false;
   if (p.epi == EPI_VT && (p.R || p.bias2 || p.vt_n0 % 320 != 0 || p.vt_S % 256 != 0 || p.vt_ld % 8 != 0 || ((uintptr_t)p.vt & 15))) return false;
   // folded LayerNorm: measured against the alternatives on one box -- K = 320 rows stay on the streaming kernel, and for the
   // GEGLU shapes (N = 8 C) the separate LayerNorm kernel + plain wide GEMM is as fast or faster (row statistics cost 32 VALU
   // instructions per k-chunk inside the MFMA phase); the narrow projections (N <= 3 C) gain 25-30 %
-  static const bool vt320 = getenv("TANGO_WIDE_VT320") != nullptr;       // experiment switch: level-0 q | k | v^T projection too
-  if (p.ln_fold && (p.epi == EPI_GEGLU || (p.K < 640 && !(vt320 && p.epi == EPI_VT)))) return false;
+  if (p.ln_fold && (p.epi == EPI_GEGLU || p.K < 640)) return false;
   if (p.e_act != ACT_NONE) return false;            // (an inlined activation switch per element bloated this kernel 10x: not supported here)
   if (p.M % 256 != 0 || p.N % 320 != 0 || (p.K * 2) % 64 != 0) return false;
   if (p.ldo % 8 != 0 || ((uintptr_t)p.out & 15) || (p.R && (p.ldr % 8 != 0 || ((uintptr_t)p.R & 15)))) return false;
   if ((p.lda * 2) % 16 != 0 || (p.Kp * 2) % 16 != 0 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
   if (((uintptr_t)p.bias & 15) || ((uintptr_t)p.bias2 & 15) || (p.bias2 && p.bias2_stride % 4 != 0)) return false;
-  static const bool force = getenv("TANGO_FORCE_DMA_GEMM") != nullptr;   // tests: exercise this kernel on small shapes
-  const long tiles = (long)(p.M / 256) * (p.N / 320) * (p.splitk > 1 ? p.splitk : 1);
-  return force || tiles >= 224;
-}
-
-// split-K factor the wide GEMM wants for a linear whose 256 x 320 tiling does not fill the chip (0: not a wide-GEMM problem)
-int gemm_wide_pick_splitk(int dtype, const GemmParams& p) {
-  static const bool force = getenv("TANGO_FORCE_DMA_GEMM") != nullptr;
-  if (force || dtype == DT_F32 || p.mode != GATHER_1D || p.M % 256 != 0 || p.N % 320 != 0 || p.K % 32 != 0 || p.K < 640) return 0;
   const long tiles = (long)(p.M / 256) * (p.N / 320);
-  if (tiles >= 224 || tiles < 16) return 0;
-  int s = (int)((256 + tiles / 2) / tiles);          // one workgroup per CU
-  if (s > p.K / 32 / 8) s = p.K / 32 / 8;            // >= 8 k-chunks per split
-  if (s < 2) return 0;
-  GemmParams q = p;
-  float dummy_ws = 0.f;
-  q.splitk = s; q.ws = &dummy_ws;
-  return gemm_wide_ok(dtype, q) ? s : 0;
+  return tuning().force_big_kernels || tiles >= 224;
 }
 
 template <typename T, bool GEGLU, bool RES, bool LN, bool VT = false, bool SK = false>
@@ -247,15 +239,16 @@ static int launch_wide_cfg(const GemmParams& p, hipStream_t s) {
     TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
-  static const int pp_mode = getenv("TANGO_PP_HALF") ? atoi(getenv("TANGO_PP_HALF")) : 0;   // 0: waves w, w + 4 (one workgroup per CU: they share a SIMD, tools/simd_probe); 1: read HW_ID (+1 us per tile)
-  static const bool tracing_env = getenv("TANGO_WIDE_TRACE") != nullptr;                    // diagnostic: per-workgroup phase times
-  const bool tracing = tracing_env && p.splitk <= 1;
+  const int pp_mode = 0;   // static half assignment: waves w and w + 4 share a SIMD (tools/simd_probe.hip)
   const unsigned grid = (unsigned)((p.M / 256) * (p.N / 320));
   unsigned long long* trace = nullptr;
+#ifdef TANGO_WIDE_TRACE_BUILD
+  const bool tracing = getenv("TANGO_WIDE_TRACE") != nullptr && p.splitk <= 1;
   if (tracing) TANGO_HIP(hipMalloc((void**)&trace, (size_t)grid * 40));
-  hipLaunchKernelGGL(kfn, dim3(grid, (unsigned)(p.splitk > 1 ? p.splitk : 1)), dim3(512), LDS, s, p, pp_mode, trace);
+#endif
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS, s, p, pp_mode, trace);
   TANGO_HIP(hipGetLastError());
-  if (p.splitk > 1) TANGO_TRY(launch_splitk_reduce(TypeTag<T>::dt, p, s));
+#ifdef TANGO_WIDE_TRACE_BUILD
   if (tracing) {
     std::vector<unsigned long long> h((size_t)grid * 5);
     TANGO_HIP(hipStreamSynchronize(s));
@@ -273,12 +266,12 @@ static int launch_wide_cfg(const GemmParams& p, hipStream_t s) {
             "epilogue issue %.2f us, store drain %.2f us\n",
             p.M, p.N, p.K, p.epi, p.R ? 1 : 0, grid, (double)(t1 - t0) * 0.01, pro / grid * 0.01, loop / grid * 0.01, epi / grid * 0.01, ack / grid * 0.01);
   }
+#endif
   return 0;
 }
 
 template <typename T>
 static int launch_wide_t(const GemmParams& p, hipStream_t s) {
-  if (p.splitk > 1) return launch_wide_cfg<T, false, false, false, false, true>(p, s);
   if (p.epi == EPI_VT) return p.ln_fold ? launch_wide_cfg<T, false, false, true, true>(p, s) : launch_wide_cfg<T, false, false, false, true>(p, s);
   if (p.ln_fold) {
     if (p.epi == EPI_GEGLU) return p.R ? launch_wide_cfg<T, true, true, true>(p, s) : launch_wide_cfg<T, true, false, true>(p, s);

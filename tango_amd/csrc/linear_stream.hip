@@ -15,6 +15,7 @@
 #include <cstdint>
 
 #include "common.h"
+#include "tuning.h"
 
 namespace tango {
 
@@ -364,10 +365,9 @@ static int stream_launch(const GemmParams& p, hipStream_t s) {
   if (rpx < 1) rpx = 1;
   const int ngroups = (p.M + 31) / 32;
   while (rpx > 1 && 8 * rpx * 8 > ngroups) --rpx;   // keep >= 8 row groups (one per wave) per workgroup
-  static const bool no_stage = getenv("TANGO_NO_STAGED_EPILOGUE") != nullptr;   // experiment switch
   GemmParams q = p;
   constexpr int EPVH = 16 / (int)sizeof(T);
-  q.stage_epi = (!no_stage && p.ldo % EPVH == 0 && ((uintptr_t)p.out & 15) == 0 && (p.epi != EPI_GEGLU || (BN / 2) % EPVH == 0)) ? 1 : 0;
+  q.stage_epi = (p.ldo % EPVH == 0 && ((uintptr_t)p.out & 15) == 0 && (p.epi != EPI_GEGLU || (BN / 2) % EPVH == 0)) ? 1 : 0;
   hipLaunchKernelGGL(kfn, dim3((unsigned)(8 * NP * rpx)), dim3(512), LDS, s, q);
   TANGO_HIP(hipGetLastError());
   return 0;
@@ -375,8 +375,7 @@ static int stream_launch(const GemmParams& p, hipStream_t s) {
 
 // can this GEMM run on the streaming kernel?
 bool linear_stream_ok(int dtype, const GemmParams& p) {
-  static const bool off = getenv("TANGO_NO_STREAM") != nullptr;   // experiment switch (plain linears only)
-  if (off && !p.ln_fold) return false;
+  if (tuning().no_stream && !p.ln_fold) return false;
   const int esz = dtype == DT_F32 ? 4 : 2;
   const int rowb = p.K * esz;
   if (p.mode != GATHER_1D || p.taps != 1 || p.rows_pb != p.M || p.in_mul != 1 || p.in_off != 0 || p.out_mul != 1 || p.out_off != 0)
@@ -406,10 +405,9 @@ static int stream_t(const GemmParams& p, hipStream_t s) {
   const int rowb = p.K * (int)sizeof(T);
   if (rowb == 640) return p.ln_fold ? stream_launch<T, 10, 10, true>(p, s) : stream_launch<T, 10, 10, false>(p, s);
   if (rowb == 1280) {
-    if constexpr (sizeof(T) == 2 && TypeTag<T>::dt == DT_BF16) {   // the unfixed build exists for the reproducing configuration only
-      static const bool nofix = getenv("TANGO_STREAM_NOFIX") != nullptr;
-      if (p.ln_fold && nofix) return stream_launch<T, 20, 5, true, false>(p, s);
-    }
+    // (the FIX = false instantiation -- the epilogue form that miscompared 39 / 300 on the bf16 K = 640 LN build,
+    //  profiles/r2_race_hunt.txt -- is no longer compiled into the library: tools/experiments/README.md says how to rebuild it;
+    //  tools/isa_scan.py checks every shipped kernel for the instruction pattern it had)
     return p.ln_fold ? stream_launch<T, 20, 5, true>(p, s) : stream_launch<T, 20, 5, false>(p, s);
   }
   TANGO_FAIL("linear_stream: unsupported K");

@@ -1,0 +1,43 @@
+// Every run-time switch of the kernel dispatch layer, in ONE place, read once per process.
+//
+// The product path needs none of them: the defaults below are what the benchmark and the drop-in API run.  They exist for
+//   (a) the parity / determinism tests, which must reach the 8-wave kernels with test-sized problems, and
+//   (b) A/B measurements inside one process or one gpurun call (tools/profile_unet_ops.py): taking a kernel family out of
+//       the dispatch shows what it buys on the real UNet shapes.
+// Experiments that were measured and decided in rounds 1-2 (persistent GEMM, ping-pong variants of the 256 x 160 kernels,
+// halo-conv ablation hooks, the un-patched streaming-LN epilogue, per-workgroup phase traces, split-K granularity sweeps)
+// are no longer compiled into libtango_hip.so; their sources live under tools/experiments/ with the evidence in profiles/.
+#pragma once
+#include <cstdlib>
+
+namespace tango {
+
+struct Tuning {
+  bool force_big_kernels;   // TANGO_FORCE_DMA_GEMM=1   tests: 8-wave LDS-DMA kernels accept grids that do not fill the chip
+  bool no_wide_conv;        // TANGO_NO_WIDE_CONV=1     A/B: conv3x3_wide_kernel (256 x 320 halo conv) out of the dispatch
+  bool no_wide_gemm;        // TANGO_NO_WIDE_GEMM=1     A/B: gemm_wide_kernel (256 x 320 GEMM) out
+  bool no_halo_conv;        // TANGO_NO_HALO_CONV=1     A/B: conv3x3_halo_kernel (256 x 160 halo conv) out
+  bool no_dma_gemm;         // TANGO_NO_DMA_GEMM=1      A/B: gemm_dma_kernel (256 x 160 gather GEMM) out
+  bool no_stream;           // TANGO_NO_STREAM=1        A/B: lin_stream_kernel out (plain linears only; folded-LN shapes need it)
+  bool no_xattn_fused;      // TANGO_NO_XATTN_FUSED=1   A/B: fused cross-attention block kernel out (round 3)
+  bool no_gn_fused_stats;   // TANGO_NO_GN_EPI_STATS=1  A/B: GroupNorm statistics from the producer's epilogue out (round 3)
+};
+
+inline const Tuning& tuning() {
+  static const Tuning t = [] {
+    auto on = [](const char* k) { const char* v = getenv(k); return v != nullptr && v[0] != '0'; };
+    Tuning x;
+    x.force_big_kernels = on("TANGO_FORCE_DMA_GEMM");
+    x.no_wide_conv = on("TANGO_NO_WIDE_CONV");
+    x.no_wide_gemm = on("TANGO_NO_WIDE_GEMM");
+    x.no_halo_conv = on("TANGO_NO_HALO_CONV");
+    x.no_dma_gemm = on("TANGO_NO_DMA_GEMM");
+    x.no_stream = on("TANGO_NO_STREAM");
+    x.no_xattn_fused = on("TANGO_NO_XATTN_FUSED");
+    x.no_gn_fused_stats = on("TANGO_NO_GN_EPI_STATS");
+    return x;
+  }();
+  return t;
+}
+
+}  // namespace tango

@@ -28,9 +28,14 @@ def p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def repeat(lib, call, out_shape, ref, tol, what):
+#: the 16-bit K = 640 folded-LayerNorm build of the streaming kernel is the family that miscompared in rounds 1-2 (39 of 300
+#: with the un-patched epilogue, profiles/r2_race_hunt.txt): it always runs at >= 300 repetitions
+REPS_LN640 = max(REPS, 300)
+
+
+def repeat(lib, call, out_shape, ref, tol, what, reps=None):
     first = None
-    for rep in range(REPS):
+    for rep in range(reps or REPS):
         out = torch.zeros(out_shape, device="cuda")
         rc = call(out)
         assert rc == 0, lib.tango_last_error().decode()
@@ -65,12 +70,12 @@ def test_stream_linear_ln_repeat(lib, dtype, M, N, K, geglu, res):
     ref = (h + r if res else h).cpu()
     repeat(lib, lambda out: lib.tango_op_linear_ln(DT[dtype], p(x), p(w), p(b), p(ga), p(be), p(r), p(out), M, N, K, geglu,
                                                    C.c_float(1e-5), None),
-           (M, No), ref, 2 * TOL[dtype], "linear_ln %s M=%d N=%d K=%d" % (dtype, M, N, K))
+           (M, No), ref, 2 * TOL[dtype], "linear_ln %s M=%d N=%d K=%d" % (dtype, M, N, K), reps=REPS_LN640 if K == 640 else None)
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "fp32"])
 @pytest.mark.parametrize("M,N,K,res", [(4130, 320, 320, 1), (8200, 640, 640, 0),       # streaming kernel, plain
-                                       (131072, 320, 1280, 1), (65536, 1280, 256, 0),   # LDS-DMA GEMM, large grids (persistent variant when TANGO_PERS_GEMM=1)
+                                       (131072, 320, 1280, 1), (65536, 1280, 256, 0),   # LDS-DMA GEMM, large grids
                                        (115000, 320, 1280, 1),                          # one-shot wide LDS-DMA GEMM (ragged M)
                                        (300, 640, 1280, 1), (512, 1280, 5120, 0)])      # 4-wave tile kernel, split-K
 def test_linear_repeat(lib, dtype, M, N, K, res):
@@ -169,7 +174,7 @@ def test_linear_qkv_vt_repeat(lib, dtype, B, S, Ch, K, ln):
 
 @pytest.mark.parametrize("dtype,M,C,K", [("fp16", 32768, 640, 640), ("bf16", 32768, 640, 640), ("fp16", 16384, 1280, 1280), ("fp32", 32768, 320, 512)])
 def test_persistent_gemm_geglu_repeat(lib, dtype, M, C, K):
-    """LDS-DMA GEMM (gemm_dma.hip; gemm_pers.hip under TANGO_PERS_GEMM=1) with the fused GEGLU epilogue: x [M, K] @ W [8C, K] -> value * gelu(gate) [M, 4C]
+    """LDS-DMA GEMM (gemm_dma.hip) with the fused GEGLU epilogue: x [M, K] @ W [8C, K] -> value * gelu(gate) [M, 4C]
     (>= 512 tiles of 256 x 128; the plain / residual epilogue of that kernel is covered by test_linear_repeat's large cases)"""
     g = torch.Generator().manual_seed(M + C + K)
     x = q(torch.randn(M, K, generator=g), dtype).cuda()

@@ -288,3 +288,25 @@ def test_predictor_gives_each_model_its_own_text_encoder(tmp_path):
     got.clear()
     Predictor().setup(model_cache=str(tmp_path), tango_cls=FakeTango, text_encoder="engine")
     assert got == ["engine", "engine"]
+
+
+def test_isa_scan_finds_no_streaming_miscompare_pattern():
+    """VERDICT r2 next #6 / ADVICE r2: no shipped kernel contains the `ds_read -> v_xor 0x80000000 -> v_pk_fma_f32` data flow
+    of the round-1/2 streaming-kernel miscompare (tools/isa_scan.py disassembles every gfx950 code object of the library; the
+    folded-LayerNorm epilogues are the strict set), and the experiment variants are no longer compiled in."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "tango_amd", "lib", "libtango_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_scan.py"), "--lib", lib, "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    tot = [l for l in r.stdout.splitlines() if l.startswith("# totals")][0]
+    assert "xor_fed 0," in tot and "both 0" in tot, tot
+    ln = [l for l in r.stdout.splitlines() if "[LN]" in l]
+    assert len(ln) >= 10, "folded-LayerNorm kernels must be recognised by name (%d found)" % len(ln)
+    names = r.stdout
+    assert "gemm_pers_kernel" not in names and "Lb1ELb0EEEvNS_10GemmParamsE" not in "".join(l for l in names.splitlines() if "lin_stream" in l)
+    # ablation / lock-step variants of the 256 x 160 kernels are not instantiated any more
+    assert not [l for l in names.splitlines() if "conv3x3_halo_kernel" in l and ("Lb1ELb0E" in l or "Lb0ELb1E" in l)]

@@ -23,6 +23,128 @@
 
 namespace tango {
 
+// the same for counts up to 40 (persistent GEMM: DMA pieces + the previous tile's epilogue stores); larger counts wait for 40
+__device__ __forceinline__ void wait_vmcnt_upto40(const int n) {
+#define TANGO_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n < 0 ? 0 : (n > 40 ? 40 : n)) {
+    TANGO_VMC(0) TANGO_VMC(1) TANGO_VMC(2) TANGO_VMC(3) TANGO_VMC(4) TANGO_VMC(5) TANGO_VMC(6) TANGO_VMC(7) TANGO_VMC(8) TANGO_VMC(9)
+    TANGO_VMC(10) TANGO_VMC(11) TANGO_VMC(12) TANGO_VMC(13) TANGO_VMC(14) TANGO_VMC(15) TANGO_VMC(16) TANGO_VMC(17) TANGO_VMC(18) TANGO_VMC(19)
+    TANGO_VMC(20) TANGO_VMC(21) TANGO_VMC(22) TANGO_VMC(23) TANGO_VMC(24) TANGO_VMC(25) TANGO_VMC(26) TANGO_VMC(27) TANGO_VMC(28) TANGO_VMC(29)
+    TANGO_VMC(30) TANGO_VMC(31) TANGO_VMC(32) TANGO_VMC(33) TANGO_VMC(34) TANGO_VMC(35) TANGO_VMC(36) TANGO_VMC(37) TANGO_VMC(38) TANGO_VMC(39)
+    TANGO_VMC(40)
+  }
+#undef TANGO_VMC
+}
+
+
+// (moved here from gemm_device.h with the kernel: only the persistent GEMM used it)
+// 16-rows-per-pass variant for the persistent GEMM (gemm_pers.hip): the staging area is ONE operand stage (the other two
+// hold the next tile's first chunks, already in flight), so each wave parks 16 rows x (TN*16) fp32 at a time.  Same fp32
+// arithmetic and order as gemm_epilogue_staged -> bit-identical results.  Returns nothing; the number of global store
+// instructions a wave issues is TM * ceil(16 * ppr / 64) (ppr = 16-byte pieces per output row) -- the caller's vmcnt
+// bookkeeping depends on it, so rows are NOT predicated here (the caller guarantees M % 256 == 0).
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_staged16(const GemmParams& p, f32x4 (&acc)[TN][TM], const int m_base, const int n_base,
+                                                       const int lane, unsigned char* stage) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  constexpr int WN = TN * 16;
+  constexpr int PITCH = WN * 4 + 16;
+  constexpr int PPR = WN / EPV;
+  const int g4 = (lane >> 4) * 4;
+  const bool geglu = p.epi == EPI_GEGLU;
+  const float* bias = p.bias;
+  const float* bias2 = p.bias2 ? p.bias2 + (int64_t)(p.step_ptr ? *p.step_ptr : 0) * p.bias2_stride : nullptr;
+  float cb[TN][4];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n_base + a * 16 + g4 + r;
+      float c = 0.f;
+      if (bias) c = bias[n];
+      if (bias2) c += bias2[n];
+      cb[a][r] = c;
+    }
+  const T* Rb = (const T*)p.R;
+  T* Ob = (T*)p.out;
+  const int ppr = geglu ? PPR / 2 : PPR;
+  // nit wave passes over the 16 x ppr pieces of a 16-row block (wave-uniform count: every executed pass issues exactly one
+  // store instruction, partially masked in the last one).  vmcnt retires in order and counts stores, so a residual load
+  // issued BEHIND a block's stores would wait for those stores to complete: the residual pieces of block b+1 are fetched
+  // before block b's stores are issued (double-buffered in registers).
+  constexpr int NIT = (16 * PPR + 63) / 64;
+  const int nit = (16 * ppr + 63) >> 6;
+  const int ncol0 = geglu ? (n_base >> 1) : n_base;
+  T rv[2][NIT][EPV];
+  auto fetch_res = [&](const int b, T (&dst)[NIT][EPV]) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = lane + it * 64;
+      if (it < nit && idx < 16 * ppr) {
+        const int rl = idx / ppr, pcs = idx - rl * ppr;
+        __builtin_memcpy(dst[it], Rb + (int64_t)(m_base + b * 16 + rl) * p.ldr + ncol0 + pcs * EPV, 16);
+      }
+    }
+  };
+  if (Rb) fetch_res(0, rv[0]);
+#pragma unroll
+  for (int b = 0; b < TM; ++b) {
+    const int row_l = lane & 15;
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+      if (geglu && (a & 1)) continue;
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha + cb[a][r];
+      if (geglu) {
+        const int ag = a + 1 < TN ? a + 1 : a;
+        float gt[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gt[r] = acc[ag][b][r] * p.alpha + cb[ag][r];
+        glu_gate4<T>(v, gt, p.glu_tanh);
+      } else if (p.e_act != ACT_NONE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.e_act, p.e_slope);
+      }
+      *(f32x4*)(stage + row_l * PITCH + ((geglu ? (a >> 1) : a) * 16 + g4) * 4) = v;
+    }
+    if (Rb && b + 1 < TM) fetch_res(b + 1, rv[(b + 1) & 1]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (it < nit) {                                  // wave-uniform
+        const int idx = lane + it * 64;
+        if (idx < 16 * ppr) {
+          const int rl = idx / ppr, pcs = idx - rl * ppr;
+          const int m = m_base + b * 16 + rl;
+          float f[EPV];
+#pragma unroll
+          for (int q = 0; q < EPV / 4; ++q) {
+            const f32x4 t = *(const f32x4*)(stage + rl * PITCH + (pcs * EPV + q * 4) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f[q * 4 + r] = t[r];
+          }
+          if (Rb) {
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) f[e] += to_f(rv[b & 1][it][e]);
+          }
+          if (p.out_scale != 1.f) {
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) f[e] *= p.out_scale;
+          }
+          T tv[EPV];
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) tv[e] = from_f<T>(f[e]);
+          __builtin_memcpy(Ob + (int64_t)m * p.ldo + ncol0 + pcs * EPV, tv, 16);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+
+
 template <typename T, int BN>
 __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(const GemmParams p, const unsigned char* zero_page, const int total_tiles) {
   constexpr int EPV = 16 / (int)sizeof(T);
