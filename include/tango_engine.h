@@ -12,6 +12,8 @@
  *   tango_engine_vae_encode     AutoencoderKL.encode (encode_first_stage)  audioldm/variational_autoencoder/autoencoder.py:52-58,112-113
  *   tango_engine_vocode         AutoencoderKL.decode_to_waveform           audioldm/variational_autoencoder/autoencoder.py:66-69
  *                               -> vocoder_infer                           audioldm/hifigan/utilities.py:76-86
+ *   tango_engine_mel_spectrogram  TacotronSTFT.mel_spectrogram            audioldm/audio/stft.py:164-186 (+ STFT.transform :52-85)
+ *   tango_engine_encode_text    T5EncoderModel forward (text_encoder(...)[0])  models.py:139-141,279-281,291-293
  *   tango_engine_set_weight     load_state_dict of pytorch_model_main.bin / pytorch_model_vae.bin   tango.py:22-28
  *
  * Conventions
@@ -93,6 +95,10 @@ typedef struct tango_config {
    * vae_* fields above); weights are the `encoder.*` / `quant_conv.*` tensors of pytorch_model_vae.bin */
   int32_t vae_encoder;
   int32_t vae_in_channels;                    /* ddconfig["in_channels"] (1) */
+  /* wave -> log-mel front-end (audioldm/audio/stft.py:136-186 TacotronSTFT; config keys of stft_config.json / models.py:40-47):
+   * built when stft_filter_length > 0 (fp32 engines only); weights are the module's buffers `mel_basis` [n_mel, n_fft/2+1] and
+   * `stft_fn.forward_basis` [2*(n_fft/2+1), 1, n_fft] (pytorch_model_stft.bin, tango.py:23-27) */
+  int32_t stft_filter_length, stft_hop_length, stft_n_mel;
 } tango_config_t;
 
 typedef struct tango_denoise_args {
@@ -151,6 +157,14 @@ int tango_engine_vocoder_samples(tango_engine_t* h, int mel_frames);
  * input_ids int64 [B, L] (device), attention_mask uint8 [B, L] (device, 1 = token, may be NULL), out fp32 [B, L, d_model] */
 int tango_engine_encode_text(tango_engine_t* h, const int64_t* input_ids, const uint8_t* attention_mask, float* out, int batch,
                              int text_len, void* stream);
+
+/* TacotronSTFT.mel_spectrogram (audioldm/audio/stft.py:164-186; callers tools/torch_tools.py:57-78): wav fp32 [B, n_samples]
+ * in [-1, 1] (device) -> mel fp32 [B, n_mel, T] = log(clamp(mel_basis @ |STFT|, 1e-5)), log_magnitudes fp32 [B, n_fft/2+1, T]
+ * (may be NULL), energy fp32 [B, T] (may be NULL); T = 1 + n_samples / hop (tango_engine_mel_frames), also returned via
+ * *n_frames (may be NULL).  n_samples must exceed n_fft / 2 (reflect padding). */
+int tango_engine_mel_frames(tango_engine_t* h, int n_samples);
+int tango_engine_mel_spectrogram(tango_engine_t* h, const float* wav, float* mel, float* log_magnitudes, float* energy, int batch,
+                                 int n_samples, int* n_frames, void* stream);
 
 /* timing of the last denoise call's kernels, measured with HIP events on the launch stream */
 int tango_engine_last_denoise_ms(tango_engine_t* h, float* total_ms, float* per_step_ms);

@@ -13,6 +13,8 @@ Every fixture is produced by importing the reference's own code (oracle/ref_impo
   loop_ref.npz         models.py:224-249 loop (fork UNet + fork DDPMScheduler, global-RNG draws), 3 steps
   vae_voc_ref.npz      reference AutoencoderKL.decode_first_stage / decode_to_waveform outputs
   vae_enc_ref.npz      reference AutoencoderKL.encode_first_stage / get_first_stage_encoding outputs
+  stft_ref.npz         reference TacotronSTFT.mel_spectrogram (audioldm/audio/stft.py:164-186) outputs on a seeded test signal
+                       (librosa stubbed by oracle/stft_oracle.py's restatements: pins everything downstream of the filterbank)
 Inputs are re-derived from seeds by the tests; only small slices / checksums / tiny state_dicts are stored.
 """
 import json
@@ -239,13 +241,40 @@ def vae_enc_golden():
     print("vae enc", checksum(mom), checksum(z))
 
 
+def stft_wave(B=2, N=20000, seed=1):
+    """deterministic test signal for the mel front-end: two partials + noise, a quiet stretch and a full-scale click (re-derived by the tests)"""
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(N, dtype=torch.float64) / 16000.0
+    y = 0.4 * torch.sin(2 * np.pi * 440 * t) + 0.2 * torch.sin(2 * np.pi * 3000 * t + 1) + 0.05 * torch.randn(N, generator=g, dtype=torch.float64)
+    y[N // 2:N // 2 + 2000] *= 1e-4          # near-silence: exercises the 1e-5 clamp
+    y[777] = 1.0
+    y = y.clamp(-1, 1).float()
+    return torch.stack([torch.roll(y, 777 * b) * (0.5 ** b) for b in range(B)])
+
+
+def stft_golden():
+    """reference TacotronSTFT (audioldm/audio/stft.py:136-186, librosa stubbed: oracle/ref_import.py tacotron_stft_cls) on stft_wave()"""
+    from oracle import stft_oracle as S
+    ref = R.tacotron_stft_cls()(**S.AUDIOLDM_STFT_CONFIG).eval()
+    y = stft_wave()
+    mel, logmag, energy = ref.mel_spectrogram(y)
+    np.savez_compressed(os.path.join(OUT, "stft_ref.npz"), mel=mel.numpy(), logmag_slice=logmag[:, ::9, ::5].numpy().copy(),
+                        logmag_checksum=np.asarray(checksum(logmag)), energy=energy.numpy(),
+                        mel_basis_checksum=np.asarray(checksum(ref.mel_basis)), basis_checksum=np.asarray(checksum(ref.stft_fn.forward_basis)))
+    print("stft", mel.shape, checksum(mel), checksum(logmag))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     assert R.available(), "needs /root/reference"
+    if len(sys.argv) > 1 and sys.argv[1] == "stft":      # regenerate only the (round-3) front-end fixture
+        stft_golden()
+        sys.exit(0)
     sched_golden()
     kat_golden()
     unet_golden()
     vae_golden()
     vae_enc_golden()
+    stft_golden()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -15,6 +15,17 @@ import os
 import sys
 import types
 
+import importlib.machinery
+
+
+def _stub(name):
+    """empty module with a real ModuleSpec: other packages probe optional dependencies with importlib.util.find_spec(), which
+    raises on a sys.modules entry whose __spec__ is None (transformers.audio_utils does, for soundfile and librosa)"""
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    return m
+
+
 REF = os.environ.get("TANGO_REFERENCE", "/root/reference")
 _FORK = os.path.join(REF, "mustango", "diffusers", "src", "diffusers")
 
@@ -50,7 +61,7 @@ def _setup():
             try:
                 __import__(stub)
             except Exception:
-                sys.modules[stub] = types.ModuleType(stub)
+                sys.modules[stub] = _stub(stub)
     if "audioldm" not in sys.modules:
         pkg = types.ModuleType("audioldm")
         pkg.__path__ = [os.path.join(REF, "audioldm")]
@@ -63,6 +74,14 @@ def unet_cls():
     from diffusers.models.unet_2d_condition import UNet2DConditionModel
 
     return UNet2DConditionModel
+
+
+def unet_music_cls():
+    """mustango/diffusers/src/diffusers/models/unet_2d_condition_music.py UNet2DConditionModelMusic (Mustango)"""
+    _setup()
+    from diffusers.models.unet_2d_condition_music import UNet2DConditionModelMusic
+
+    return UNet2DConditionModelMusic
 
 
 def ddpm_cls():
@@ -91,6 +110,36 @@ def autoencoder_cls():
     from audioldm.variational_autoencoder.autoencoder import AutoencoderKL
 
     return AutoencoderKL
+
+
+def tacotron_stft_cls():
+    """audioldm/audio/stft.py:136 `TacotronSTFT`.  stft.py:5-6 and audio_processing.py:3 import librosa, which is neither in
+    /root/reference nor installed (requirements.txt pins librosa==0.9.2): a stub module provides the three functions they
+    use -- `librosa.util.pad_center`, `librosa.util.tiny`, `librosa.util.normalize` (only window_sumsquare's inverse path) and
+    `librosa.filters.mel` -- from oracle/stft_oracle.py's restatements.  So a run of the imported class pins everything
+    DOWNSTREAM of the filterbank (window, DFT basis, reflect padding, conv1d framing, magnitude, matmul, log-clamp, energy);
+    the filterbank itself is pinned to transformers.audio_utils.mel_filter_bank instead (oracle/stft_oracle.py header)."""
+    _setup()
+    import numpy as np
+
+    from oracle import stft_oracle as S
+    if "librosa" not in sys.modules:
+        lib, util, filters = _stub("librosa"), _stub("librosa.util"), _stub("librosa.filters")
+        util.pad_center = lambda data, size, axis=-1, **kw: S.pad_center(np.asarray(data), size)
+        util.tiny = lambda x: np.finfo(np.asarray(x).dtype if np.issubdtype(np.asarray(x).dtype, np.floating) else np.float32).tiny
+        util.normalize = lambda x, norm=None, **kw: x
+        filters.mel = lambda sr, n_fft, n_mels=128, fmin=0.0, fmax=None, **kw: S.slaney_mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+        lib.util, lib.filters = util, filters
+        sys.modules["librosa"], sys.modules["librosa.util"], sys.modules["librosa.filters"] = lib, util, filters
+    # audioldm/audio/__init__.py imports tools.py -> torchaudio (absent; only the wav-file reader uses it): register the
+    # sub-package path-only, like `audioldm` itself, so that only stft.py / audio_processing.py execute
+    if "audioldm.audio" not in sys.modules:
+        pkg = types.ModuleType("audioldm.audio")
+        pkg.__path__ = [os.path.join(REF, "audioldm", "audio")]
+        sys.modules["audioldm.audio"] = pkg
+    from audioldm.audio.stft import TacotronSTFT
+
+    return TacotronSTFT
 
 
 def unet_config(name="diffusion_model_config.json"):

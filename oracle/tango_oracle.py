@@ -349,21 +349,40 @@ def transformer_2d(sd: SD, p: str, x, heads, enc, enc_bias, groups=32):
     return h + res
 
 
+def _mask_bias(mask, dtype):
+    """bool mask [B, L] (True = keep) -> additive bias [B, 1, L] (unet_2d_condition.py:575-579; _music.py:603-623)"""
+    if mask is None:
+        return None
+    return ((1 - mask.to(dtype)) * -10000.0).unsqueeze(1)
+
+
 def unet_forward(sd: SD, cfg: dict, sample, timestep, encoder_hidden_states,
-                 encoder_attention_mask=None, prefix: str = "") -> torch.Tensor:
-    """fork models/unet_2d_condition.py:520-707 for the Tango configuration.
+                 encoder_attention_mask=None, prefix: str = "", beat_features=None, chord_features=None,
+                 beat_attention_mask=None, chord_attention_mask=None) -> torch.Tensor:
+    """fork models/unet_2d_condition.py:520-707 for the Tango configuration, and -- when `beat_features` / `chord_features` are
+    given -- Mustango's UNet2DConditionModelMusic.forward (models/unet_2d_condition_music.py:536-757): every cross-attention
+    site runs THREE Transformer2DModels in sequence, `attentions` on the text, `attentions2` on the beat embeddings and
+    `attentions3` on the chord embeddings, each with its own mask bias (unet_2d_blocks.py:1199-1260 CrossAttnDownBlock2DMusic,
+    :715-757 UNetMidBlock2DCrossAttnMusic, :2372-2436 CrossAttnUpBlock2DMusic).
 
     sample [B2,8,256,16] NCHW; timestep python int / 0-d tensor; encoder_hidden_states [B2,L,d];
-    encoder_attention_mask bool [B2,L] (True = keep)."""
+    encoder_attention_mask bool [B2,L] (True = keep); beat / chord features [B2,Lb|Lc,d] with bool masks."""
+    music = beat_features is not None
     cfg = normalize_unet_config(cfg)
     chans = cfg["block_out_channels"]
     heads = cfg["attention_head_dim"]
     groups, eps = cfg["norm_num_groups"], cfg["norm_eps"]
     P = prefix
-    bias = None
-    if encoder_attention_mask is not None:                   # :575-579
-        bias = (1 - encoder_attention_mask.to(sample.dtype)) * -10000.0
-        bias = bias.unsqueeze(1)
+    conds = [("attentions", encoder_hidden_states, _mask_bias(encoder_attention_mask, sample.dtype))]
+    if music:
+        conds.append(("attentions2", beat_features, _mask_bias(beat_attention_mask, sample.dtype)))
+        conds.append(("attentions3", chord_features, _mask_bias(chord_attention_mask, sample.dtype)))
+
+    def xattn(h, site, j, nheads):
+        for name, feats, bias in conds:
+            h = transformer_2d(sd, f"{P}{site}.{name}.{j}", h, nheads, feats, bias, groups)
+        return h
+
     ts = torch.as_tensor(timestep).reshape(-1).expand(sample.shape[0])         # :586-600
     t_emb = timestep_embedding(ts, chans[0], cfg["flip_sin_to_cos"], cfg["freq_shift"])
     emb = _lin(sd, P + "time_embedding.linear_1", t_emb)     # embeddings.py:200-212
@@ -374,25 +393,23 @@ def unet_forward(sd: SD, cfg: dict, sample, timestep, encoder_hidden_states,
     for i, btype in enumerate(cfg["down_block_types"]):      # unet_2d_blocks.py:935-1074,1273-1349
         for j in range(cfg["layers_per_block"]):
             h = resnet_block_2d(sd, f"{P}down_blocks.{i}.resnets.{j}", h, emb, groups, eps)
-            if btype == "CrossAttnDownBlock2D":
-                h = transformer_2d(sd, f"{P}down_blocks.{i}.attentions.{j}", h, heads[i],
-                                   encoder_hidden_states, bias, groups)
+            if btype in ("CrossAttnDownBlock2D", "CrossAttnDownBlock2DMusic"):
+                h = xattn(h, f"down_blocks.{i}", j, heads[i])
             skips.append(h)
         if i != len(chans) - 1:                              # resnet.py:164-208, stride 2 pad 1
             h = _conv(sd, f"{P}down_blocks.{i}.downsamplers.0.conv", h, stride=2, padding=1)
             skips.append(h)
     # mid: unet_2d_blocks.py:492-598
     h = resnet_block_2d(sd, P + "mid_block.resnets.0", h, emb, groups, eps)
-    h = transformer_2d(sd, P + "mid_block.attentions.0", h, heads[-1], encoder_hidden_states, bias, groups)
+    h = xattn(h, "mid_block", 0, heads[-1])
     h = resnet_block_2d(sd, P + "mid_block.resnets.1", h, emb, groups, eps)
     rheads = list(reversed(heads))
     for i, btype in enumerate(cfg["up_block_types"]):        # unet_2d_blocks.py:2112-2248,2442-2513
         for j in range(cfg["layers_per_block"] + 1):
             h = torch.cat([h, skips.pop()], dim=1)
             h = resnet_block_2d(sd, f"{P}up_blocks.{i}.resnets.{j}", h, emb, groups, eps)
-            if btype == "CrossAttnUpBlock2D":
-                h = transformer_2d(sd, f"{P}up_blocks.{i}.attentions.{j}", h, rheads[i],
-                                   encoder_hidden_states, bias, groups)
+            if btype in ("CrossAttnUpBlock2D", "CrossAttnUpBlock2DMusic"):
+                h = xattn(h, f"up_blocks.{i}", j, rheads[i])
         if i != len(chans) - 1:                              # resnet.py:95-161 nearest x2 + conv
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
             h = _conv(sd, f"{P}up_blocks.{i}.upsamplers.0.conv", h)
@@ -406,8 +423,9 @@ def unet_forward(sd: SD, cfg: dict, sample, timestep, encoder_hidden_states,
 
 def denoise_loop(sd: SD, cfg: dict, scheduler, prompt_embeds, boolean_prompt_mask, latents,
                  num_steps: int, guidance_scale: float, noises: Optional[Sequence[torch.Tensor]] = None,
-                 prefix: str = "", callback=None) -> torch.Tensor:
-    """models.py:224-249.  `prompt_embeds` is [2B,L,d] ordered [uncond; cond] when guidance > 1
+                 prefix: str = "", callback=None, music: Optional[dict] = None) -> torch.Tensor:
+    """models.py:224-249 (and mustango/models.py:540-598 when `music` = dict(beat_features, chord_features, beat_attention_mask,
+    chord_attention_mask), all ordered [uncond; cond] like the text embeddings).  `prompt_embeds` is [2B,L,d] ordered [uncond; cond] when guidance > 1
     (models.py:301), `latents` [B,8,256,16] is draw #1 (models.py:259-264) already scaled by
     init_noise_sigma, `noises[i]` is the randn drawn inside scheduler.step at loop index i (only
     consumed when t > 0)."""
@@ -416,7 +434,7 @@ def denoise_loop(sd: SD, cfg: dict, scheduler, prompt_embeds, boolean_prompt_mas
     for i, t in enumerate(scheduler.timesteps):
         inp = torch.cat([latents] * 2) if cfg_on else latents
         inp = scheduler.scale_model_input(inp, t)
-        out = unet_forward(sd, cfg, inp, t, prompt_embeds, boolean_prompt_mask, prefix)
+        out = unet_forward(sd, cfg, inp, t, prompt_embeds, boolean_prompt_mask, prefix, **(music or {}))
         if cfg_on:
             u, c = out.chunk(2)
             out = u + guidance_scale * (c - u)

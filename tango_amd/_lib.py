@@ -60,6 +60,9 @@ class TangoConfig(C.Structure):
         ("t5_eps", C.c_float),
         ("vae_encoder", C.c_int32),
         ("vae_in_channels", C.c_int32),
+        ("stft_filter_length", C.c_int32),
+        ("stft_hop_length", C.c_int32),
+        ("stft_n_mel", C.c_int32),
     ]
 
 
@@ -91,6 +94,7 @@ SYMBOLS = [
     "tango_engine_num_weights", "tango_engine_weight_name", "tango_engine_set_weight",
     "tango_engine_finalize_weights", "tango_engine_denoise", "tango_engine_unet_forward",
     "tango_engine_vae_decode", "tango_engine_vae_encode", "tango_engine_vocode", "tango_engine_vocoder_samples", "tango_engine_encode_text",
+    "tango_engine_mel_frames", "tango_engine_mel_spectrogram",
     "tango_engine_last_denoise_ms", "tango_engine_profile_unet", "tango_op_conv2d", "tango_op_linear", "tango_op_linear_ln", "tango_op_linear_qkv", "tango_op_conv1d",
     "tango_op_conv_transpose1d", "tango_op_groupnorm", "tango_op_layernorm", "tango_op_attention",
     "tango_op_sched_step", "tango_op_philox_normal",
@@ -127,6 +131,8 @@ def load():
     lib.tango_engine_vocode.argtypes = [vp, vp, vp, ci, ci, C.POINTER(ci), vp]
     lib.tango_engine_vocoder_samples.argtypes = [vp, ci]
     lib.tango_engine_encode_text.argtypes = [vp, vp, vp, vp, ci, ci, vp]
+    lib.tango_engine_mel_frames.argtypes = [vp, ci]
+    lib.tango_engine_mel_spectrogram.argtypes = [vp, vp, vp, vp, vp, ci, ci, C.POINTER(ci), vp]
     lib.tango_engine_last_denoise_ms.argtypes = [vp, C.POINTER(cf), C.POINTER(cf)]
     lib.tango_engine_profile_unet.argtypes = [vp, ci, ci, C.c_char_p, ci, vp]
     lib.tango_op_conv2d.argtypes = [ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]

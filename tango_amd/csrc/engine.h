@@ -141,6 +141,12 @@ struct VaePlan {           // also used for the vocoder: plan-owned in/out stagi
   int n_out = 0;            // vocoder: samples per item
 };
 
+struct StftPlan {          // wave -> log-mel front-end buffers for one (batch, n_samples)
+  int B = 0, N = 0, T = 0, Np = 0, Kp2 = 0, ldz = 0;
+  char* slab = nullptr;
+  float *in = nullptr, *xpad = nullptr, *Z = nullptr, *mag = nullptr, *mel_lin = nullptr, *mel = nullptr, *logmag = nullptr, *energy = nullptr;
+};
+
 class Engine {
  public:
   explicit Engine(const tango_config_t& c);
@@ -156,6 +162,7 @@ class Engine {
   int vocode(const float* mel, int16_t* wav, int B, int frames, int* n_samples, hipStream_t s);
   int vocoder_samples(int frames) const;
   int encode_text(const int64_t* ids, const uint8_t* mask, float* out, int B, int L, hipStream_t s);
+  int mel_spectrogram(const float* wav, float* mel, float* logmag, float* energy, int B, int N, int* n_frames, hipStream_t s);
   int last_denoise_ms(float* total_ms, float* per_step_ms);
   int profile_unet(int B2, int L, std::string& report, hipStream_t s);
 
@@ -192,6 +199,7 @@ class Engine {
   void reg_vae_attn(const std::string& p, int C, VaeAttnW& w);
   void build_voc_weights();
   void build_t5_weights();
+  void build_stft_weights();       // frontend.hip
 
   // ---- model weights ----
   // UNet
@@ -226,6 +234,11 @@ class Engine {
   WMat voc_pre, voc_post;
   std::vector<ConvTW> voc_ups;
   std::vector<VocResW> voc_res;
+
+  // wave -> log-mel front-end (frontend.hip)
+  WMat stft_basis, stft_mel;
+  std::map<std::pair<int, int>, std::unique_ptr<StftPlan>> stft_plans;
+  int get_stft_plan(int B, int N, StftPlan** out);
 
   // text encoder
   float* t5_embed = nullptr;        // [vocab][d_model] fp32
@@ -267,3 +280,6 @@ class Engine {
 };
 
 }  // namespace tango
+
+// the opaque handle of include/tango_engine.h
+struct tango_engine { tango::Engine* e; };

@@ -292,6 +292,7 @@ Engine::~Engine() {
   for (auto& kv : vae_enc_plans) if (kv.second->slab) (void)hipFree(kv.second->slab);
   for (auto& kv : voc_plans) if (kv.second->slab) (void)hipFree(kv.second->slab);
   for (auto& kv : t5_plans) if (kv.second->slab) (void)hipFree(kv.second->slab);
+  for (auto& kv : stft_plans) if (kv.second->slab) (void)hipFree(kv.second->slab);
   for (void* p : owned) (void)hipFree(p);
   if (cap_stream) (void)hipStreamDestroy(cap_stream);
   if (ev0) (void)hipEventDestroy(ev0);
@@ -685,6 +686,12 @@ int Engine::init() {
     if (cfg.t5_d_kv != 64) TANGO_FAIL("engine: T5 d_kv must be 64 (attention head_dim)");
     if (cfg.t5_d_model % 16 || cfg.t5_d_ff % 16) TANGO_FAIL("engine: T5 d_model / d_ff must be multiples of 16");
     build_t5_weights();
+  }
+  if (cfg.stft_filter_length > 0) {
+    if (dt != DT_F32) TANGO_FAIL("engine: the STFT front-end runs on an fp32 engine only (frontend.hip)");
+    if (cfg.stft_filter_length % 16 || cfg.stft_hop_length <= 0 || cfg.stft_hop_length % 4 || cfg.stft_n_mel <= 0)
+      TANGO_FAIL("engine: STFT front-end needs filter_length % 16 == 0, hop_length % 4 == 0, n_mel > 0");
+    build_stft_weights();
   }
   for (void* p : owned) if (!p) return -1;
   TANGO_HIP(hipEventCreate(&ev0));
@@ -1500,7 +1507,6 @@ int Engine::vocode(const float* mel, int16_t* wav, int B, int frames, int* n_sam
 // C ABI
 // ================================================================================================
 using tango::Engine;
-struct tango_engine { Engine* e; };
 
 extern "C" {
 

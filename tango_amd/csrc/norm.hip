@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 }
 
 // Normalise + affine (+ SiLU).  The former gn_finalize launch is folded in: every workgroup reduces the per-chunk partial
-// sums of ITS sample (chunks x groups pairs, double accumulation in chunk order -- the same arithmetic as before, so the
-// results are bit-identical) and derives scale / shift for its own channels; 61 launches per UNet step fewer.
+// sums of ITS sample (chunks x groups pairs, double accumulation in a fixed order -- deterministic) and derives scale / shift
+// for its own channels; 61 launches per UNet step fewer.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
                                                        const float* __restrict__ partial, const float* __restrict__ gamma,
@@ -143,16 +143,37 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
                                                        int rows, int C, int act, int VPR, int TPR, int RPB, int RC) {
   constexpr int EPV = 16 / (int)sizeof(T);
   __shared__ float mean_s[256], rstd_s[256];
+  __shared__ double part_s[2][256], tot_s[2][256];
   const int tid = threadIdx.x;
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int cg = C / groups;
-  if (tid < groups) {
-    double a = 0.0, q = 0.0;
-    for (int ch = 0; ch < chunks; ++ch) {
-      const float* o = partial + (((int64_t)b * chunks + ch) * groups + tid) * 2;
-      a += (double)o[0]; q += (double)o[1];
+  // Per-sample reduction of the chunk partials, spread over the whole workgroup: `lanes` threads per group each sum every
+  // lanes-th chunk (double, fixed order), the group's first thread then adds the `lanes` sub-sums in fixed order.  (Round 2
+  // had ONE thread per group walk all chunks: at B = 8 that is a chain of 128 loads at the head of every workgroup -- the
+  // level-0 GroupNorm ran at 1.4 TB/s there, profiles/r2_unet_ops_small_batch_splitk.txt.)
+  int lanes = 256 / groups;                         // groups <= 256 (checked by the launcher)
+  if (lanes > 8) lanes = 8;
+  {
+    const int g = tid / lanes, sub = tid - g * lanes;
+    if (g < groups) {
+      double a = 0.0, q = 0.0;
+      for (int ch = sub; ch < chunks; ch += lanes) {
+        const f32x2 o = *(const f32x2*)(partial + (((int64_t)b * chunks + ch) * groups + g) * 2);
+        a += (double)o.x; q += (double)o.y;
+      }
+      part_s[0][tid] = a; part_s[1][tid] = q;
     }
+    __syncthreads();
+    if (g < groups && sub == 0) {
+      double a = 0.0, q = 0.0;
+      for (int k = 0; k < lanes; ++k) { a += part_s[0][tid + k]; q += part_s[1][tid + k]; }
+      tot_s[0][g] = a; tot_s[1][g] = q;
+    }
+  }
+  __syncthreads();
+  if (tid < groups) {
     const double n = (double)rows * cg;
+    const double a = tot_s[0][tid], q = tot_s[1][tid];
     const double mean = a / n;
     double var = q / n - mean * mean;
     if (var < 0.0) var = 0.0;

@@ -53,7 +53,8 @@ class Engine:
     """One engine handle = one (device, model) pair; not re-entrant (include/tango_engine.h)."""
 
     def __init__(self, unet: Optional[dict] = None, vae: Optional[dict] = None, hifigan: Optional[dict] = None,
-                 dtype: str = "fp16", device="cuda:0", t5: Optional[dict] = None, vae_encoder: bool = False):
+                 dtype: str = "fp16", device="cuda:0", t5: Optional[dict] = None, vae_encoder: bool = False,
+                 stft: Optional[dict] = None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("tango_amd.Engine needs a HIP device (no CPU fallback)")
@@ -64,6 +65,7 @@ class Engine:
         self.hifigan_cfg = dict(hifigan) if hifigan is not None else None
         self.t5_cfg = dict(t5) if t5 is not None else None
         self.vae_encoder = bool(vae_encoder) and vae is not None
+        self.stft_cfg = dict(stft) if stft is not None else None
         c = _lib.TangoConfig()
         c.dtype = _lib.DTYPES[dtype]
         c.latent_h, c.latent_w = 256, 16
@@ -116,6 +118,9 @@ class Engine:
             c.t5_rel_buckets = t.get("relative_attention_num_buckets", 32)
             c.t5_rel_max_distance = t.get("relative_attention_max_distance", 128)
             c.t5_eps = t.get("layer_norm_epsilon", 1e-6)
+        if self.stft_cfg is not None:
+            c.stft_filter_length, c.stft_hop_length = self.stft_cfg["filter_length"], self.stft_cfg["hop_length"]
+            c.stft_n_mel = self.stft_cfg["n_mel_channels"]
         self._cfg = c
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -147,6 +152,8 @@ class Engine:
             out.update(W.hifigan_param_shapes(self.hifigan_cfg))
         if self.t5_cfg is not None:
             out.update(W.t5_encoder_param_shapes(self.t5_cfg))
+        if self.stft_cfg is not None:
+            out.update(W.stft_param_shapes(self.stft_cfg))
         return out
 
     def set_weight(self, name: str, tensor: torch.Tensor):
@@ -263,6 +270,28 @@ class Engine:
             _lib.check(self.lib.tango_engine_encode_text(self._h, C.c_void_p(ids.data_ptr()), C.c_void_p(m.data_ptr()) if m is not None else None,
                                                          C.c_void_p(out.data_ptr()), B, L, _stream_ptr()), "encode_text")
         return out
+
+    def mel_spectrogram(self, wav, want_log_magnitudes=True, want_energy=True):
+        """TacotronSTFT.mel_spectrogram on the engine: wav [B, N] fp32 in [-1, 1] -> (log-mel [B, n_mel, T],
+        log-magnitudes [B, n_fft/2+1, T] or None, energy [B, T] or None), T = 1 + N // hop"""
+        if self.stft_cfg is None:
+            raise RuntimeError("Engine was created without an stft config")
+        y = self._f32(wav)
+        if y.dim() != 2:
+            raise ValueError("mel_spectrogram: wav must be [B, n_samples], got %s" % (tuple(y.shape),))
+        B, N = y.shape
+        T = self.lib.tango_engine_mel_frames(self._h, N)
+        cutoff = self.stft_cfg["filter_length"] // 2 + 1
+        mel = torch.empty((B, self.stft_cfg["n_mel_channels"], T), device=self.device, dtype=torch.float32)
+        lm = torch.empty((B, cutoff, T), device=self.device, dtype=torch.float32) if want_log_magnitudes else None
+        en = torch.empty((B, T), device=self.device, dtype=torch.float32) if want_energy else None
+        nf = C.c_int()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.tango_engine_mel_spectrogram(
+                self._h, C.c_void_p(y.data_ptr()), C.c_void_p(mel.data_ptr()), C.c_void_p(lm.data_ptr()) if lm is not None else None,
+                C.c_void_p(en.data_ptr()) if en is not None else None, B, N, C.byref(nf), _stream_ptr()), "mel_spectrogram")
+        assert nf.value == T
+        return mel, lm, en
 
     def vae_decode(self, latents):
         z = self._f32(latents)

@@ -19,14 +19,16 @@ from .scheduler import DDIMScheduler, DDPMScheduler  # noqa: F401  (re-exported 
 _TEXT_BUCKETS = (16, 32, 64, 128, 256, 512)
 
 
-def build_pretrained_models(ckpt, vae_config=None, dtype="fp16", device="cuda:0", autoencoder_cls=None):
-    """models.py:27-52 of the reference: build the mel-VAE (+ vocoder) from an AudioLDM `.ckpt`
-    (`{"state_dict": {"first_stage_model.*": ..., "scale_factor": ...}}`); `ckpt` is a path or an already loaded dict.
-    Returns `(vae, None)`: the second item of the reference is the TacotronSTFT wave->mel front-end, which only the
-    training / evaluation side uses and is not built here.  `vae_config` defaults to the AudioLDM
-    first-stage config (audioldm/utils.py:158-181 == mustango/configs/vae_config.json)."""
+def build_pretrained_models(ckpt, vae_config=None, dtype="fp16", device="cuda:0", autoencoder_cls=None, stft_config=None, stft_cls=None):
+    """models.py:27-52 of the reference: build the mel-VAE (+ vocoder) and the TacotronSTFT wave->mel front-end from an AudioLDM
+    `.ckpt` (`{"state_dict": {"first_stage_model.*": ..., "scale_factor": ...}}`); `ckpt` is a path or an already loaded dict.
+    Returns `(vae, fn_STFT)` like the reference.  `vae_config` defaults to the AudioLDM first-stage config
+    (audioldm/utils.py:158-181 == mustango/configs/vae_config.json), `stft_config` to its preprocessing block
+    (audioldm/utils.py:104-118: n_fft 1024, hop 160, 64 mels, 16 kHz, 0-8000 Hz)."""
     if autoencoder_cls is None:
         from .autoencoder import AutoencoderKL as autoencoder_cls
+    if stft_cls is None:
+        from .stft import TacotronSTFT as stft_cls
     checkpoint = torch.load(ckpt, map_location="cpu") if isinstance(ckpt, (str, os.PathLike)) else ckpt
     sd = checkpoint["state_dict"]
     scale_factor = float(sd["scale_factor"].item() if hasattr(sd["scale_factor"], "item") else sd["scale_factor"])
@@ -38,8 +40,13 @@ def build_pretrained_models(ckpt, vae_config=None, dtype="fp16", device="cuda:0"
     cfg["scale_factor"] = scale_factor
     vae = autoencoder_cls(**cfg, dtype=dtype, device=device)
     vae.load_state_dict(vae_state_dict)
+    sc = dict(stft_config) if stft_config is not None else dict(filter_length=1024, hop_length=160, win_length=1024, n_mel_channels=64,
+                                                                 sampling_rate=16000, mel_fmin=0, mel_fmax=8000)
+    fn_STFT = stft_cls(sc["filter_length"], sc["hop_length"], sc["win_length"], sc["n_mel_channels"], sc["sampling_rate"],
+                       sc["mel_fmin"], sc["mel_fmax"], device=device)
     vae.eval()
-    return vae, None
+    fn_STFT.eval()
+    return vae, fn_STFT
 
 
 def _hf_classes():

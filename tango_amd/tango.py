@@ -28,6 +28,14 @@ class Tango:
         vae_config = json.load(open("{}/vae_config.json".format(path)))
         main_config = json.load(open("{}/main_config.json".format(path)))
         self.vae = AutoencoderKL(**vae_config, dtype=dtype, device=device)
+        # tango.py:17-27: the wave -> mel front-end and its buffers (generation never calls it; training / evaluation callers
+        # reach it as `tango.stft`, inference.py:81).  Snapshots without the two files simply have no `stft`.
+        self.stft = None
+        if os.path.exists("{}/stft_config.json".format(path)) and os.path.exists("{}/pytorch_model_stft.bin".format(path)):
+            from .stft import TacotronSTFT
+            self.stft = TacotronSTFT(**json.load(open("{}/stft_config.json".format(path))), device=device)
+            self.stft.load_state_dict(torch.load("{}/pytorch_model_stft.bin".format(path), map_location="cpu"))
+            self.stft.eval()
         cfg_path = main_config.get("unet_model_config_path")
         if cfg_path is None or not os.path.exists(cfg_path):
             # the reference resolves configs/diffusion_model_config.json relative to the cwd (models.py:83-85)
@@ -49,7 +57,7 @@ class Tango:
     def from_components(cls, model: AudioDiffusion, vae: AutoencoderKL, scheduler=None):
         """Assemble from already-built components (synthetic-weight benchmarks, tests)."""
         self = cls.__new__(cls)
-        self.model, self.vae = model, vae
+        self.model, self.vae, self.stft = model, vae, None
         self.scheduler = scheduler or DDPMScheduler.from_config(_ddpm_keys(SD21_SCHEDULER_CONFIG))
         return self
 

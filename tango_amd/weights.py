@@ -252,6 +252,13 @@ def t5_encoder_param_shapes(cfg: dict, prefix: str = "text_encoder.") -> Shapes:
     return out
 
 
+def stft_param_shapes(cfg: dict, prefix: str = "") -> Shapes:
+    """buffers of audioldm/audio/stft.py TacotronSTFT the front-end reads (pytorch_model_stft.bin; `stft_fn.inverse_basis` is
+    not on the wave -> mel path)"""
+    cutoff = cfg["filter_length"] // 2 + 1
+    return {prefix + "stft_fn.forward_basis": (2 * cutoff, 1, cfg["filter_length"]), prefix + "mel_basis": (cfg["n_mel_channels"], cutoff)}
+
+
 def t5_config_from_state_dict(sd, prefix: str = "text_encoder.") -> dict:
     """Recover the encoder hyper-parameters from the tensors themselves (a checkpoint carries no config.json for them)."""
     d = sd[prefix + "shared.weight"].shape[1] if prefix + "shared.weight" in sd else sd[prefix + "encoder.embed_tokens.weight"].shape[1]

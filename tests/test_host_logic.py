@@ -212,8 +212,16 @@ def test_build_pretrained_models_from_audioldm_ckpt():
 
     ck = {"state_dict": {"scale_factor": torch.tensor(0.9227914214134216), "first_stage_model.decoder.conv_in.weight": torch.zeros(2),
                          "first_stage_model.vocoder.conv_pre.bias": torch.ones(3), "model.diffusion_model.x": torch.zeros(1)}}
-    vae, stft = build_pretrained_models(ck, autoencoder_cls=FakeVAE)
-    assert stft is None and isinstance(vae, FakeVAE)
+    class FakeSTFT:
+        def __init__(self, *a, **kw):
+            seen["stft"] = (a, kw)
+
+        def eval(self):
+            return self
+
+    vae, stft = build_pretrained_models(ck, autoencoder_cls=FakeVAE, stft_cls=FakeSTFT)
+    assert isinstance(stft, FakeSTFT) and isinstance(vae, FakeVAE)
+    assert seen["stft"][0] == (1024, 160, 1024, 64, 16000, 0, 8000)       # audioldm/utils.py:104-118 via models.py:40-47
     assert abs(seen["kw"]["scale_factor"] - 0.9227914214134216) < 1e-7 and seen["kw"]["ddconfig"]["ch_mult"] == [1, 2, 4]
     assert sorted(seen["sd"]) == ["decoder.conv_in.weight", "vocoder.conv_pre.bias"]
 
