@@ -8,6 +8,7 @@
  *                               + DDPMScheduler.step                       mustango/diffusers/src/diffusers/schedulers/scheduling_ddpm.py:254-349
  *                               (+ DDIMScheduler.step                      .../scheduling_ddim.py:238-360)
  *   tango_engine_unet_forward   UNet2DConditionModel.forward               mustango/diffusers/src/diffusers/models/unet_2d_condition.py:520-707
+ *   tango_engine_unet_forward_music  UNet2DConditionModelMusic.forward      mustango/diffusers/src/diffusers/models/unet_2d_condition_music.py:536-757
  *   tango_engine_vae_decode     AutoencoderKL.decode_first_stage           audioldm/variational_autoencoder/autoencoder.py:116-124,60-64
  *   tango_engine_vae_encode     AutoencoderKL.encode (encode_first_stage)  audioldm/variational_autoencoder/autoencoder.py:52-58,112-113
  *   tango_engine_vocode         AutoencoderKL.decode_to_waveform           audioldm/variational_autoencoder/autoencoder.py:66-69
@@ -99,6 +100,12 @@ typedef struct tango_config {
    * built when stft_filter_length > 0 (fp32 engines only); weights are the module's buffers `mel_basis` [n_mel, n_fft/2+1] and
    * `stft_fn.forward_basis` [2*(n_fft/2+1), 1, n_fft] (pytorch_model_stft.bin, tango.py:23-27) */
   int32_t stft_filter_length, stft_hop_length, stft_n_mel;
+  /* Mustango's UNet2DConditionModelMusic (mustango/diffusers/src/diffusers/models/unet_2d_condition_music.py; config
+   * mustango/configs/music_diffusion_model_config.json: CrossAttn{Down,Up}Block2DMusic / UNetMidBlock2DCrossAttnMusic): every
+   * cross-attention site holds THREE Transformer2DModels applied in sequence -- `attentions` (text), `attentions2` (beat
+   * embeddings), `attentions3` (chord embeddings), unet_2d_blocks.py:1199-1260,715-757,2372-2436.  All three conditions have
+   * width unet_cross_dim. */
+  int32_t unet_music;
 } tango_config_t;
 
 typedef struct tango_denoise_args {
@@ -119,6 +126,15 @@ typedef struct tango_denoise_args {
   uint64_t seed;               /* Philox key when noise == NULL */
   int32_t sample_offset;       /* global index of local sample 0 (keeps Philox noise independent of the DP sharding) */
   int32_t use_graph;           /* 1: replay the captured hipGraph of the UNet step; 0: eager launches */
+  /* Music UNet only (cfg.unet_music; mustango/models.py:540-598 MusicAudioDiffusion.inference): beat / chord condition
+   * embeddings [B2, beat_len | chord_len, d] fp32 with bool masks [B2, len] (may be NULL), ordered [uncond; cond] like
+   * prompt_embeds (mustango/models.py:650-740).  Ignored (may be NULL / 0) for the plain UNet. */
+  const float* beat_embeds;
+  const uint8_t* beat_mask;
+  int32_t beat_len;
+  const float* chord_embeds;
+  const uint8_t* chord_mask;
+  int32_t chord_len;
 } tango_denoise_args_t;
 
 const char* tango_last_error(void);
@@ -142,6 +158,13 @@ int tango_engine_denoise(tango_engine_t* h, const tango_denoise_args_t* args, vo
 /* one UNet call: sample [B2,C,H,W] fp32 NCHW, timestep, embeds [B2,L,d], mask [B2,L] -> out [B2,C,H,W] fp32 */
 int tango_engine_unet_forward(tango_engine_t* h, const float* sample, int64_t timestep, const float* prompt_embeds,
                               const uint8_t* prompt_mask, float* out, int batch2, int text_len, void* stream);
+
+/* UNet2DConditionModelMusic.forward (unet_2d_condition_music.py:536-757): as tango_engine_unet_forward plus the beat / chord
+ * conditions [B2, beat_len | chord_len, d] fp32 and their bool masks (may be NULL) */
+int tango_engine_unet_forward_music(tango_engine_t* h, const float* sample, int64_t timestep, const float* prompt_embeds,
+                                    const uint8_t* prompt_mask, const float* beat_embeds, const uint8_t* beat_mask,
+                                    const float* chord_embeds, const uint8_t* chord_mask, float* out, int batch2, int text_len,
+                                    int beat_len, int chord_len, void* stream);
 
 /* latents [B,8,256,16] fp32 -> mel [B,1,1024,64] fp32 */
 int tango_engine_vae_decode(tango_engine_t* h, const float* latents, float* mel, int batch, void* stream);

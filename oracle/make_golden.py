@@ -13,6 +13,7 @@ Every fixture is produced by importing the reference's own code (oracle/ref_impo
   loop_ref.npz         models.py:224-249 loop (fork UNet + fork DDPMScheduler, global-RNG draws), 3 steps
   vae_voc_ref.npz      reference AutoencoderKL.decode_first_stage / decode_to_waveform outputs
   vae_enc_ref.npz      reference AutoencoderKL.encode_first_stage / get_first_stage_encoding outputs
+  music_unet_ref.npz   Mustango UNet2DConditionModelMusic.forward (unet_2d_condition_music.py:536-757) output slices, tiny widths
   stft_ref.npz         reference TacotronSTFT.mel_spectrogram (audioldm/audio/stft.py:164-186) outputs on a seeded test signal
                        (librosa stubbed by oracle/stft_oracle.py's restatements: pins everything downstream of the filterbank)
 Inputs are re-derived from seeds by the tests; only small slices / checksums / tiny state_dicts are stored.
@@ -241,6 +242,39 @@ def vae_enc_golden():
     print("vae enc", checksum(mom), checksum(z))
 
 
+def music_inputs(cfg, B2, seed, L=9, Lb=50, Lc=20):
+    """seeded Music-UNet inputs (re-derived by the tests): ragged text mask, uncond rows with ALL beat / chord tokens masked
+    (what the empty uncond beat / chord lists tokenise to, mustango/models.py:664-676,713-727), ragged cond rows"""
+    g = torch.Generator().manual_seed(seed)
+    d = cfg["cross_attention_dim"]
+    x = torch.randn(B2, 8, 256, 16, generator=g)
+    enc, beat, chord = torch.randn(B2, L, d, generator=g), torch.randn(B2, Lb, d, generator=g), torch.randn(B2, Lc, d, generator=g)
+    em, bm, cm = torch.ones(B2, L, dtype=torch.bool), torch.ones(B2, Lb, dtype=torch.bool), torch.ones(B2, Lc, dtype=torch.bool)
+    h = B2 // 2
+    em[:h, 1:] = False
+    bm[:h] = False
+    cm[:h] = False
+    bm[h:, 17:] = False
+    cm[h:, 5:] = False
+    return x, enc, beat, chord, em, bm, cm
+
+
+def music_golden():
+    """Mustango's UNet2DConditionModelMusic (unet_2d_condition_music.py:536-757) with the seeded synthetic weights, tiny widths"""
+    cfgo = O.UNET_CONFIG_MUSIC_TINY
+    cfg = json.load(open(os.path.join(R.REF, "mustango", "configs", "music_diffusion_model_config.json")))
+    cfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
+    cfg.update({k: cfgo[k] for k in ("block_out_channels", "attention_head_dim", "cross_attention_dim")})
+    unet = R.unet_music_cls()(**cfg).eval()
+    unet.load_state_dict(W.synth_state_dict(W.unet_param_shapes(cfgo), 1234))
+    x, enc, beat, chord, em, bm, cm = music_inputs(cfgo, 4, 3)
+    out = unet(x, torch.tensor(801), encoder_hidden_states=enc, beat_features=beat, chord_features=chord, encoder_attention_mask=em,
+               beat_attention_mask=bm, chord_attention_mask=cm).sample
+    np.savez_compressed(os.path.join(OUT, "music_unet_ref.npz"), out_slice=out[:, :, ::9, ::3].numpy().copy(),
+                        out_checksum=np.asarray(checksum(out)), n_tensors=np.asarray(len(unet.state_dict())))
+    print("music unet", checksum(out))
+
+
 def stft_wave(B=2, N=20000, seed=1):
     """deterministic test signal for the mel front-end: two partials + noise, a quiet stretch and a full-scale click (re-derived by the tests)"""
     g = torch.Generator().manual_seed(seed)
@@ -267,8 +301,8 @@ def stft_golden():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     assert R.available(), "needs /root/reference"
-    if len(sys.argv) > 1 and sys.argv[1] == "stft":      # regenerate only the (round-3) front-end fixture
-        stft_golden()
+    if len(sys.argv) > 1 and sys.argv[1] in ("stft", "music"):      # regenerate only a round-3 fixture
+        {"stft": stft_golden, "music": music_golden}[sys.argv[1]]()
         sys.exit(0)
     sched_golden()
     kat_golden()
@@ -276,5 +310,6 @@ if __name__ == "__main__":
     vae_golden()
     vae_enc_golden()
     stft_golden()
+    music_golden()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -51,6 +51,15 @@ UNET_CONFIG_TINY = dict(
     cross_attention_dim=96,
 )
 
+#: mustango/configs/music_diffusion_model_config.json (Mustango): the Tango UNet with *Music cross-attention blocks
+UNET_CONFIG_MUSIC = dict(
+    UNET_CONFIG_LARGE,
+    down_block_types=["CrossAttnDownBlock2DMusic"] * 3 + ["DownBlock2D"],
+    up_block_types=["UpBlock2D"] + ["CrossAttnUpBlock2DMusic"] * 3,
+)
+UNET_CONFIG_MUSIC_TINY = dict(UNET_CONFIG_MUSIC, block_out_channels=[64, 128, 256, 256], attention_head_dim=[1, 2, 4, 4],
+                              cross_attention_dim=96)
+
 #: mustango/configs/vae_config.json == audioldm/utils.py:158-181
 VAE_CONFIG = dict(ch=128, ch_mult=[1, 2, 4], num_res_blocks=2, z_channels=8, out_ch=1, embed_dim=8,
                   scale_factor=0.9227914214134216)

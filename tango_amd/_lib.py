@@ -63,6 +63,7 @@ class TangoConfig(C.Structure):
         ("stft_filter_length", C.c_int32),
         ("stft_hop_length", C.c_int32),
         ("stft_n_mel", C.c_int32),
+        ("unet_music", C.c_int32),
     ]
 
 
@@ -85,6 +86,12 @@ class DenoiseArgs(C.Structure):
         ("seed", C.c_uint64),
         ("sample_offset", C.c_int32),
         ("use_graph", C.c_int32),
+        ("beat_embeds", C.c_void_p),
+        ("beat_mask", C.c_void_p),
+        ("beat_len", C.c_int32),
+        ("chord_embeds", C.c_void_p),
+        ("chord_mask", C.c_void_p),
+        ("chord_len", C.c_int32),
     ]
 
 
@@ -92,7 +99,7 @@ class DenoiseArgs(C.Structure):
 SYMBOLS = [
     "tango_last_error", "tango_version", "tango_engine_create", "tango_engine_destroy",
     "tango_engine_num_weights", "tango_engine_weight_name", "tango_engine_set_weight",
-    "tango_engine_finalize_weights", "tango_engine_denoise", "tango_engine_unet_forward",
+    "tango_engine_finalize_weights", "tango_engine_denoise", "tango_engine_unet_forward", "tango_engine_unet_forward_music",
     "tango_engine_vae_decode", "tango_engine_vae_encode", "tango_engine_vocode", "tango_engine_vocoder_samples", "tango_engine_encode_text",
     "tango_engine_mel_frames", "tango_engine_mel_spectrogram",
     "tango_engine_last_denoise_ms", "tango_engine_profile_unet", "tango_op_conv2d", "tango_op_linear", "tango_op_linear_ln", "tango_op_linear_qkv", "tango_op_conv1d",
@@ -126,6 +133,7 @@ def load():
     lib.tango_engine_finalize_weights.argtypes = [vp]
     lib.tango_engine_denoise.argtypes = [vp, C.POINTER(DenoiseArgs), vp]
     lib.tango_engine_unet_forward.argtypes = [vp, vp, i64, vp, vp, vp, ci, ci, vp]
+    lib.tango_engine_unet_forward_music.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.tango_engine_vae_decode.argtypes = [vp, vp, vp, ci, vp]
     lib.tango_engine_vae_encode.argtypes = [vp, vp, vp, ci, vp]
     lib.tango_engine_vocode.argtypes = [vp, vp, vp, ci, ci, C.POINTER(ci), vp]

@@ -1,5 +1,6 @@
 // Internal engine classes (host side).  The public surface is include/tango_engine.h.
 #pragma once
+#include <array>
 #include <functional>
 #include <map>
 #include <memory>
@@ -81,6 +82,7 @@ struct ResW {
 };
 struct XfW {             // Transformer2DModel with one BasicTransformerBlock
   int C = 0, heads = 0;
+  int cond = 0;          // which condition its cross-attention reads: 0 text, 1 beat, 2 chord (Music UNet: attentions / attentions2 / attentions3)
   WNorm gn, ln1, ln2, ln3;
   WMat proj_in, qkv, o1, q2, kv2, o2, ff1, ff2, proj_out;
 };
@@ -108,12 +110,15 @@ struct Slot {
 
 struct UNetPlan {
   int B2 = 0, L = 0;
+  int Lc[3] = {0, 0, 0};    // condition lengths: [0] text (== L), [1] beat, [2] chord (Music UNet only)
   char* slab = nullptr;
   Program pre, step;
   void* xin = nullptr;      // T  [B2*HW][8]
   float* eps = nullptr;     // f32 [B2*HW][out_ch]
-  void* enc = nullptr;      // T  [B2*L][cross]
-  float* bias = nullptr;    // f32 [B2*L]
+  void* enc = nullptr;      // T  [B2*L][cross]       (== encs[0])
+  float* bias = nullptr;    // f32 [B2*L]             (== biases[0])
+  void* encs[3] = {nullptr, nullptr, nullptr};
+  float* biases[3] = {nullptr, nullptr, nullptr};
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
 };
@@ -156,7 +161,8 @@ class Engine {
   int set_weight(const char* name, const float* dev, const int64_t* shape, int ndim);
   int finalize_weights();
   int denoise(const tango_denoise_args_t& a, hipStream_t s);
-  int unet_forward(const float* sample, int64_t t, const float* enc, const uint8_t* mask, float* out, int B2, int L, hipStream_t s);
+  struct Cond { const float* emb = nullptr; const uint8_t* mask = nullptr; int len = 0; };
+  int unet_forward(const float* sample, int64_t t, const Cond (&c)[3], float* out, int B2, hipStream_t s);
   int vae_decode(const float* lat, float* mel, int B, hipStream_t s);
   int vae_encode(const float* mel, float* moments, int B, hipStream_t s);
   int vocode(const float* mel, int16_t* wav, int B, int frames, int* n_samples, hipStream_t s);
@@ -206,12 +212,13 @@ class Engine {
   WMat conv_in, conv_out;
   WNorm norm_out;
   WLinF32 time1, time2;
-  struct DownBlock { std::vector<ResW> res; std::vector<XfW> xf; bool has_ds = false; WMat ds; };
-  struct UpBlock { std::vector<ResW> res; std::vector<XfW> xf; bool has_us = false; WMat us; };
+  // xf[j] is the site's text transformer; xf2 / xf3 are `attentions2` / `attentions3` of the Music blocks (empty otherwise)
+  struct DownBlock { std::vector<ResW> res; std::vector<XfW> xf, xf2, xf3; bool has_ds = false; WMat ds; };
+  struct UpBlock { std::vector<ResW> res; std::vector<XfW> xf, xf2, xf3; bool has_us = false; WMat us; };
   std::vector<DownBlock> down;
   std::vector<UpBlock> up;
   ResW mid_res0, mid_res1;
-  XfW mid_xf;
+  XfW mid_xf, mid_xf2, mid_xf3;
   std::vector<ResW*> all_res;   // every UNet resblock (temb tables)
   std::vector<XfW*> all_xf;
   // VAE
@@ -259,7 +266,7 @@ class Engine {
   float* d_temb = nullptr;       // [max_steps][temb]  silu(emb)
   std::vector<int64_t> temb_ts;  // cache key
   int max_steps = 1000;
-  std::map<std::pair<int, int>, std::unique_ptr<UNetPlan>> unet_plans;
+  std::map<std::array<int, 4>, std::unique_ptr<UNetPlan>> unet_plans;   // key: (B2, L_text, L_beat, L_chord)
   std::map<int, std::unique_ptr<VaePlan>> vae_plans;
   std::map<int, std::unique_ptr<VaePlan>> vae_enc_plans;
   std::map<std::pair<int, int>, std::unique_ptr<VaePlan>> voc_plans;
@@ -268,7 +275,7 @@ class Engine {
   int last_steps = 0;
 
   int ensure_temb(const int64_t* ts_host, int n, hipStream_t s);
-  int get_unet_plan(int B2, int L, UNetPlan** out);
+  int get_unet_plan(int B2, int L, int Lbeat, int Lchord, UNetPlan** out);
   int build_unet(UNetPlan& P, Arena& A, bool record);
   int get_vae_plan(int B, VaePlan** out);
   int build_vae(VaePlan& P, Arena& A, bool record);
@@ -276,7 +283,7 @@ class Engine {
   int build_vae_enc(VaePlan& P, Arena& A, bool record);
   int get_voc_plan(int B, int frames, VaePlan** out);
   int build_voc(VaePlan& P, Arena& A, bool record, int frames);
-  int bind_text(UNetPlan& P, const float* enc, const uint8_t* mask, hipStream_t s);
+  int bind_text(UNetPlan& P, const Cond (&c)[3], hipStream_t s);
 };
 
 }  // namespace tango

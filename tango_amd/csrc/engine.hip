@@ -492,11 +492,20 @@ void Engine::build_unet_weights() {
   for (int i = 0; i < nl; ++i) {
     DownBlock& d = down[i];
     d.res.resize(lpb);
-    if (cfg.unet_cross_attn[i]) d.xf.resize(lpb);
+    if (cfg.unet_cross_attn[i]) {
+      d.xf.resize(lpb);
+      if (cfg.unet_music) { d.xf2.resize(lpb); d.xf3.resize(lpb); }
+    }
     for (int j = 0; j < lpb; ++j) {
       const std::string bp = P + "down_blocks." + std::to_string(i);
       reg_res(bp + ".resnets." + std::to_string(j), j == 0 ? cprev : ch[i], ch[i], temb, eps, d.res[j], false);
-      if (cfg.unet_cross_attn[i]) reg_xf(bp + ".attentions." + std::to_string(j), ch[i], cfg.unet_heads[i], cross, d.xf[j]);
+      if (cfg.unet_cross_attn[i]) {
+        reg_xf(bp + ".attentions." + std::to_string(j), ch[i], cfg.unet_heads[i], cross, d.xf[j]);
+        if (cfg.unet_music) {   // CrossAttnDownBlock2DMusic (unet_2d_blocks.py:1079-1275)
+          reg_xf(bp + ".attentions2." + std::to_string(j), ch[i], cfg.unet_heads[i], cross, d.xf2[j]); d.xf2[j].cond = 1;
+          reg_xf(bp + ".attentions3." + std::to_string(j), ch[i], cfg.unet_heads[i], cross, d.xf3[j]); d.xf3[j].cond = 2;
+        }
+      }
     }
     if (i != nl - 1) {
       d.has_ds = true;
@@ -507,6 +516,10 @@ void Engine::build_unet_weights() {
   const int cm = ch[nl - 1];
   reg_res(P + "mid_block.resnets.0", cm, cm, temb, eps, mid_res0, false);
   reg_xf(P + "mid_block.attentions.0", cm, cfg.unet_heads[nl - 1], cross, mid_xf);
+  if (cfg.unet_music) {           // UNetMidBlock2DCrossAttnMusic (unet_2d_blocks.py:603-757)
+    reg_xf(P + "mid_block.attentions2.0", cm, cfg.unet_heads[nl - 1], cross, mid_xf2); mid_xf2.cond = 1;
+    reg_xf(P + "mid_block.attentions3.0", cm, cfg.unet_heads[nl - 1], cross, mid_xf3); mid_xf3.cond = 2;
+  }
   reg_res(P + "mid_block.resnets.1", cm, cm, temb, eps, mid_res1, false);
   up.resize(nl);
   int prev_out = ch[nl - 1];
@@ -517,13 +530,22 @@ void Engine::build_unet_weights() {
     UpBlock& u = up[i];
     const bool xa = cfg.unet_cross_attn[lvl] != 0;   // up block i mirrors down block (nl-1-i)
     u.res.resize(lpb + 1);
-    if (xa) u.xf.resize(lpb + 1);
+    if (xa) {
+      u.xf.resize(lpb + 1);
+      if (cfg.unet_music) { u.xf2.resize(lpb + 1); u.xf3.resize(lpb + 1); }
+    }
     const std::string bp = P + "up_blocks." + std::to_string(i);
     for (int j = 0; j <= lpb; ++j) {
       const int skip = (j == lpb) ? inc : outc;
       const int rin = (j == 0) ? prev_out : outc;
       reg_res(bp + ".resnets." + std::to_string(j), rin + skip, outc, temb, eps, u.res[j], false);
-      if (xa) reg_xf(bp + ".attentions." + std::to_string(j), outc, cfg.unet_heads[lvl], cross, u.xf[j]);
+      if (xa) {
+        reg_xf(bp + ".attentions." + std::to_string(j), outc, cfg.unet_heads[lvl], cross, u.xf[j]);
+        if (cfg.unet_music) {   // CrossAttnUpBlock2DMusic (unet_2d_blocks.py:2251-2436)
+          reg_xf(bp + ".attentions2." + std::to_string(j), outc, cfg.unet_heads[lvl], cross, u.xf2[j]); u.xf2[j].cond = 1;
+          reg_xf(bp + ".attentions3." + std::to_string(j), outc, cfg.unet_heads[lvl], cross, u.xf3[j]); u.xf3[j].cond = 2;
+        }
+      }
     }
     if (i != nl - 1) {
       u.has_us = true;
@@ -534,9 +556,15 @@ void Engine::build_unet_weights() {
   reg_norm(P + "conv_norm_out", ch[0], eps, norm_out);
   reg_conv3x3(P + "conv_out", cfg.unet_out_channels, ch[0], conv_out);
   // pointer lists (vectors above are final now)
-  for (auto& d : down) { for (auto& r : d.res) all_res.push_back(&r); for (auto& x : d.xf) all_xf.push_back(&x); }
+  auto push_xfs = [&](std::vector<XfW>& a, std::vector<XfW>& b, std::vector<XfW>& c) {
+    for (auto& x : a) all_xf.push_back(&x);
+    for (auto& x : b) all_xf.push_back(&x);
+    for (auto& x : c) all_xf.push_back(&x);
+  };
+  for (auto& d : down) { for (auto& r : d.res) all_res.push_back(&r); push_xfs(d.xf, d.xf2, d.xf3); }
   all_res.push_back(&mid_res0); all_res.push_back(&mid_res1); all_xf.push_back(&mid_xf);
-  for (auto& u : up) { for (auto& r : u.res) all_res.push_back(&r); for (auto& x : u.xf) all_xf.push_back(&x); }
+  if (cfg.unet_music) { all_xf.push_back(&mid_xf2); all_xf.push_back(&mid_xf3); }
+  for (auto& u : up) { for (auto& r : u.res) all_res.push_back(&r); push_xfs(u.xf, u.xf2, u.xf3); }
 }
 
 void Engine::build_vae_weights() {
@@ -780,7 +808,7 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
   Builder b{*this, A, &P.step, record, dt, esz};
   const int nl = cfg.unet_levels;
   const int* ch = cfg.unet_channels;
-  const int B2 = P.B2, L = P.L, G = cfg.unet_groups;
+  const int B2 = P.B2, G = cfg.unet_groups;
   const int lpb = cfg.unet_layers_per_block;
   auto HH = [&](int lvl) { return cfg.latent_h >> lvl; };
   auto WW = [&](int lvl) { return cfg.latent_w >> lvl; };
@@ -791,22 +819,27 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
   TView xin = b.alloc(rows_at(0), cin_pad);
   P.xin = xin.p;
   P.eps = (float*)A.alloc((size_t)rows_at(0) * cfg.unet_out_channels * 4);
-  TView enc = b.alloc((int64_t)B2 * L, cfg.unet_cross_dim);
-  P.enc = enc.p;
-  P.bias = (float*)A.alloc((size_t)B2 * L * 4);
+  const int ncond = cfg.unet_music ? 3 : 1;
+  TView encv[3];
+  for (int c = 0; c < ncond; ++c) {
+    encv[c] = b.alloc((int64_t)B2 * P.Lc[c], cfg.unet_cross_dim);
+    P.encs[c] = encv[c].p;
+    P.biases[c] = (float*)A.alloc((size_t)B2 * P.Lc[c] * 4);
+  }
+  P.enc = P.encs[0];
+  P.bias = P.biases[0];
 
   // cross-attention K/V for every transformer: step-invariant, computed by P.pre once per call
   std::vector<TView> kvs(all_xf.size());       // K  [B2*L][C]
   std::vector<void*> kvts(all_xf.size());      // V^T [B2][C][Lp], Lp = L rounded up to 8 (pad columns stay zero)
-  const int Lp = (L + 7) / 8 * 8;
   {
     Builder pb{*this, A, &P.pre, record, dt, esz};
     for (size_t i = 0; i < all_xf.size(); ++i) {
-      const int C = all_xf[i]->C;
-      kvs[i] = pb.alloc((int64_t)B2 * L, C);
-      kvts[i] = A.alloc((size_t)B2 * C * Lp * esz);
-      GOpt o; o.use_bias = false; o.vt = kvts[i]; o.vt_n0 = C; o.vt_S = L; o.vt_ld = Lp;
-      pb.linear(enc, (int64_t)B2 * L, all_xf[i]->kv2, kvs[i], o);
+      const int C = all_xf[i]->C, Li = P.Lc[all_xf[i]->cond], Lpi = (Li + 7) / 8 * 8;
+      kvs[i] = pb.alloc((int64_t)B2 * Li, C);
+      kvts[i] = A.alloc((size_t)B2 * C * Lpi * esz);
+      GOpt o; o.use_bias = false; o.vt = kvts[i]; o.vt_n0 = C; o.vt_S = Li; o.vt_ld = Lpi;
+      pb.linear(encv[all_xf[i]->cond], (int64_t)B2 * Li, all_xf[i]->kv2, kvs[i], o);
     }
   }
   auto kv_idx = [&](const XfW* w) -> size_t {
@@ -833,6 +866,21 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
       prev_out = outc;
     }
   }
+  // one cross-attention site: `attentions[j]`, then (Music UNet) `attentions2[j]` on the beats and `attentions3[j]` on the chords
+  auto xf_site = [&](const XfW& w1, const XfW* w2, const XfW* w3, const TView& x, int lvl, const TView& out) {
+    auto one = [&](const XfW& w, const TView& in, const TView& o) {
+      const size_t k = kv_idx(&w);
+      b.transformer(w, in, B2, HH(lvl), WW(lvl), G, kvs[k], kvts[k], P.biases[w.cond], P.Lc[w.cond], o);
+    };
+    if (!w2) { one(w1, x, out); return; }
+    const size_t m = A.mark();
+    TView t1 = b.alloc(rows_at(lvl), w1.C), t2 = b.alloc(rows_at(lvl), w1.C);
+    one(w1, x, t1);
+    one(*w2, t1, t2);
+    one(*w3, t2, out);
+    A.release(m);
+  };
+  const bool music = cfg.unet_music != 0;
   int skip_no = 0;
   auto skip_dst = [&]() -> TView {   // destination view of the next skip tensor
     Cat& c = cats[nup - 1 - skip_no];
@@ -850,7 +898,7 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
         TView r = b.alloc(rows_at(i), ch[i]);
         b.resblock(down[i].res[j], h, B2, HH(i), WW(i), G, r);
         TView o = skip_dst();
-        b.transformer(down[i].xf[j], r, B2, HH(i), WW(i), G, kvs[kv_idx(&down[i].xf[j])], kvts[kv_idx(&down[i].xf[j])], P.bias, L, o);
+        xf_site(down[i].xf[j], music ? &down[i].xf2[j] : nullptr, music ? &down[i].xf3[j] : nullptr, r, i, o);
         h = o;
       } else {
         TView o = skip_dst();
@@ -870,7 +918,7 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
     TView r0 = b.alloc(rows_at(lvl), ch[lvl]);
     b.resblock(mid_res0, h, B2, HH(lvl), WW(lvl), G, r0);
     TView x1 = b.alloc(rows_at(lvl), ch[lvl]);
-    b.transformer(mid_xf, r0, B2, HH(lvl), WW(lvl), G, kvs[kv_idx(&mid_xf)], kvts[kv_idx(&mid_xf)], P.bias, L, x1);
+    xf_site(mid_xf, music ? &mid_xf2 : nullptr, music ? &mid_xf3 : nullptr, r0, lvl, x1);
     TView dst = Builder::slice(cats[0].buf, 0, cats[0].c1, esz);
     b.resblock(mid_res1, x1, B2, HH(lvl), WW(lvl), G, dst);
   }
@@ -891,7 +939,7 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
       if (xa) {
         TView r = b.alloc(rows_at(lvl), outc);
         b.resblock(up[i].res[j], c.buf, B2, HH(lvl), WW(lvl), G, r);
-        b.transformer(up[i].xf[j], r, B2, HH(lvl), WW(lvl), G, kvs[kv_idx(&up[i].xf[j])], kvts[kv_idx(&up[i].xf[j])], P.bias, L, dst);
+        xf_site(up[i].xf[j], music ? &up[i].xf2[j] : nullptr, music ? &up[i].xf3[j] : nullptr, r, lvl, dst);
       } else {
         b.resblock(up[i].res[j], c.buf, B2, HH(lvl), WW(lvl), G, dst);
       }
@@ -914,13 +962,16 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
   return 0;
 }
 
-int Engine::get_unet_plan(int B2, int L, UNetPlan** out) {
-  auto key = std::make_pair(B2, L);
+int Engine::get_unet_plan(int B2, int L, int Lbeat, int Lchord, UNetPlan** out) {
+  if (cfg.unet_music && (Lbeat <= 0 || Lchord <= 0)) TANGO_FAIL("engine: the Music UNet needs beat and chord conditions (beat_len, chord_len > 0)");
+  if (!cfg.unet_music) { Lbeat = 0; Lchord = 0; }
+  const std::array<int, 4> key = {B2, L, Lbeat, Lchord};
   auto it = unet_plans.find(key);
   if (it != unet_plans.end()) { *out = it->second.get(); return 0; }
   if (!finalized) TANGO_FAIL("engine: weights not finalized");
   std::unique_ptr<UNetPlan> P(new UNetPlan());
   P->B2 = B2; P->L = L;
+  P->Lc[0] = L; P->Lc[1] = Lbeat; P->Lc[2] = Lchord;
   Arena m;
   TANGO_TRY(build_unet(*P, m, false));
   TANGO_HIP(hipMalloc((void**)&P->slab, m.peak + 256));
@@ -933,19 +984,24 @@ int Engine::get_unet_plan(int B2, int L, UNetPlan** out) {
   return 0;
 }
 
-int Engine::bind_text(UNetPlan& P, const float* enc, const uint8_t* mask, hipStream_t s) {
-  TANGO_TRY(launch_cast_rows(dt, enc, P.enc, cfg.unet_cross_dim, P.B2 * P.L, cfg.unet_cross_dim, s));
-  if (mask) TANGO_TRY(launch_mask_bias(mask, P.bias, P.B2 * P.L, s));
-  else TANGO_TRY(launch_fill_zero(P.bias, (size_t)P.B2 * P.L * 4, s));
+int Engine::bind_text(UNetPlan& P, const Cond (&c)[3], hipStream_t s) {
+  const int ncond = cfg.unet_music ? 3 : 1;
+  for (int i = 0; i < ncond; ++i) {
+    if (!c[i].emb) TANGO_FAIL("engine: missing condition embeddings");
+    const int n = P.B2 * P.Lc[i];
+    TANGO_TRY(launch_cast_rows(dt, c[i].emb, P.encs[i], cfg.unet_cross_dim, n, cfg.unet_cross_dim, s));
+    if (c[i].mask) TANGO_TRY(launch_mask_bias(c[i].mask, P.biases[i], n, s));
+    else TANGO_TRY(launch_fill_zero(P.biases[i], (size_t)n * 4, s));
+  }
   return P.pre.run(s);
 }
 
-int Engine::unet_forward(const float* sample, int64_t t, const float* enc, const uint8_t* mask, float* out, int B2, int L, hipStream_t s) {
+int Engine::unet_forward(const float* sample, int64_t t, const Cond (&c)[3], float* out, int B2, hipStream_t s) {
   UNetPlan* P;
-  TANGO_TRY(get_unet_plan(B2, L, &P));
+  TANGO_TRY(get_unet_plan(B2, c[0].len, c[1].len, c[2].len, &P));
   TANGO_TRY(ensure_temb(&t, 1, s));
   TANGO_HIP(hipMemsetAsync(d_step, 0, 4, s));
-  TANGO_TRY(bind_text(*P, enc, mask, s));
+  TANGO_TRY(bind_text(*P, c, s));
   const int HW = cfg.latent_h * cfg.latent_w;
   TANGO_TRY(launch_fill_zero(P->xin, (size_t)B2 * HW * 8 * esz, s));
   TANGO_TRY(launch_nchw_to_nhwc(dt, sample, P->xin, 8, B2, cfg.unet_in_channels, HW, 1, 1.0f, s));
@@ -959,7 +1015,7 @@ int Engine::denoise(const tango_denoise_args_t& a, hipStream_t s) {
   const bool cfg_on = a.guidance_scale > 1.0f;
   const int B = a.batch, B2 = cfg_on ? 2 * B : B;
   UNetPlan* P;
-  TANGO_TRY(get_unet_plan(B2, a.text_len, &P));
+  TANGO_TRY(get_unet_plan(B2, a.text_len, a.beat_len, a.chord_len, &P));
   TANGO_TRY(ensure_temb(a.timesteps, a.num_steps, s));
   const int HW = cfg.latent_h * cfg.latent_w;
   const int C = cfg.unet_in_channels;
@@ -975,7 +1031,13 @@ int Engine::denoise(const tango_denoise_args_t& a, hipStream_t s) {
   TANGO_HIP(hipMemcpyAsync(d_sched, &sp, sizeof(SchedParams), hipMemcpyHostToDevice, s));
   TANGO_HIP(hipStreamSynchronize(s));   // both sources are pageable / transient host memory
   TANGO_HIP(hipMemsetAsync(d_step, 0, 4, s));
-  TANGO_TRY(bind_text(*P, a.prompt_embeds, a.prompt_mask, s));
+  {
+    Cond c[3];
+    c[0].emb = a.prompt_embeds; c[0].mask = a.prompt_mask; c[0].len = a.text_len;
+    c[1].emb = a.beat_embeds; c[1].mask = a.beat_mask; c[1].len = a.beat_len;
+    c[2].emb = a.chord_embeds; c[2].mask = a.chord_mask; c[2].len = a.chord_len;
+    TANGO_TRY(bind_text(*P, c, s));
+  }
   TANGO_TRY(launch_fill_zero(P->xin, (size_t)B2 * HW * 8 * esz, s));
   TANGO_TRY(launch_nchw_to_nhwc(dt, a.latents, P->xin, 8, B, C, HW, cfg_on ? 2 : 1, 1.0f, s));
 
@@ -1031,7 +1093,7 @@ int Program::run_profiled(hipStream_t s, std::string& report) const {
 
 int Engine::profile_unet(int B2, int L, std::string& report, hipStream_t s) {
   UNetPlan* P;
-  TANGO_TRY(get_unet_plan(B2, L, &P));
+  TANGO_TRY(get_unet_plan(B2, L, cfg.unet_music ? 50 : 0, cfg.unet_music ? 20 : 0, &P));   // mustango/models.py:336,340: beat_len 50, chord_len 20
   int64_t t = 500;
   TANGO_TRY(ensure_temb(&t, 1, s));
   TANGO_HIP(hipMemsetAsync(d_step, 0, 4, s));
@@ -1548,7 +1610,19 @@ int tango_engine_denoise(tango_engine_t* h, const tango_denoise_args_t* a, void*
 }
 int tango_engine_unet_forward(tango_engine_t* h, const float* sample, int64_t timestep, const float* prompt_embeds,
                               const uint8_t* prompt_mask, float* out, int batch2, int text_len, void* stream) {
-  return h->e->unet_forward(sample, timestep, prompt_embeds, prompt_mask, out, batch2, text_len, (hipStream_t)stream);
+  Engine::Cond c[3];
+  c[0].emb = prompt_embeds; c[0].mask = prompt_mask; c[0].len = text_len;
+  return h->e->unet_forward(sample, timestep, c, out, batch2, (hipStream_t)stream);
+}
+int tango_engine_unet_forward_music(tango_engine_t* h, const float* sample, int64_t timestep, const float* prompt_embeds,
+                                    const uint8_t* prompt_mask, const float* beat_embeds, const uint8_t* beat_mask,
+                                    const float* chord_embeds, const uint8_t* chord_mask, float* out, int batch2, int text_len,
+                                    int beat_len, int chord_len, void* stream) {
+  Engine::Cond c[3];
+  c[0].emb = prompt_embeds; c[0].mask = prompt_mask; c[0].len = text_len;
+  c[1].emb = beat_embeds; c[1].mask = beat_mask; c[1].len = beat_len;
+  c[2].emb = chord_embeds; c[2].mask = chord_mask; c[2].len = chord_len;
+  return h->e->unet_forward(sample, timestep, c, out, batch2, (hipStream_t)stream);
 }
 int tango_engine_vae_encode(tango_engine_t* h, const float* mel, float* moments, int batch, void* stream) {
   return h->e->vae_encode(mel, moments, batch, (hipStream_t)stream);

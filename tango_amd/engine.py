@@ -17,6 +17,9 @@ UNET_CONFIG_LARGE = dict(
     norm_num_groups=32, norm_eps=1e-5, flip_sin_to_cos=True, freq_shift=0,
 )
 UNET_CONFIG_XL = dict(UNET_CONFIG_LARGE, cross_attention_dim=2048)
+#: mustango/configs/music_diffusion_model_config.json (Mustango's UNet2DConditionModelMusic)
+UNET_CONFIG_MUSIC = dict(UNET_CONFIG_LARGE, down_block_types=["CrossAttnDownBlock2DMusic"] * 3 + ["DownBlock2D"],
+                         up_block_types=["UpBlock2D"] + ["CrossAttnUpBlock2DMusic"] * 3)
 #: mustango/configs/vae_config.json ddconfig + scale_factor
 VAE_CONFIG = dict(ch=128, ch_mult=[1, 2, 4], num_res_blocks=2, z_channels=8, out_ch=1, embed_dim=8,
                   scale_factor=0.9227914214134216)
@@ -36,12 +39,20 @@ def normalize_unet_config(cfg: dict) -> dict:
     # the engine derives the up path from the down path (unet_2d_condition.py:330-375 builds them independently):
     # refuse configurations where up_block_types is not the mirror image instead of silently assuming it
     down, up = list(out["down_block_types"]), list(out["up_block_types"])
-    known_d, known_u = {"CrossAttnDownBlock2D", "DownBlock2D"}, {"CrossAttnUpBlock2D", "UpBlock2D"}
+    # Mustango's music UNet (mustango/configs/music_diffusion_model_config.json): the same topology with *Music cross-attention
+    # blocks (three transformers per site); a config is either all-Music or all-plain at its cross-attention sites
+    music = any(t.endswith("Music") for t in down + up)
+    xd, xu = ("CrossAttnDownBlock2DMusic", "CrossAttnUpBlock2DMusic") if music else ("CrossAttnDownBlock2D", "CrossAttnUpBlock2D")
+    known_d, known_u = {xd, "DownBlock2D"}, {xu, "UpBlock2D"}
     if set(down) - known_d or set(up) - known_u:
         raise ValueError("unsupported UNet block types %s / %s" % (down, up))
-    mirror = ["CrossAttnUpBlock2D" if d == "CrossAttnDownBlock2D" else "UpBlock2D" for d in reversed(down)]
+    mirror = [xu if d == xd else "UpBlock2D" for d in reversed(down)]
     if up != mirror or len(down) != len(out["block_out_channels"]):
         raise ValueError("up_block_types %s must mirror down_block_types %s" % (up, down))
+    mid = cfg.get("mid_block_type")
+    if mid is not None and mid != ("UNetMidBlock2DCrossAttnMusic" if music else "UNetMidBlock2DCrossAttn"):
+        raise ValueError("unsupported mid_block_type %s" % mid)
+    out["music"] = music
     return out
 
 
@@ -76,7 +87,8 @@ class Engine:
             for i, v in enumerate(ch):
                 c.unet_channels[i] = v
                 c.unet_heads[i] = u["attention_head_dim"][i]
-                c.unet_cross_attn[i] = 1 if u["down_block_types"][i] == "CrossAttnDownBlock2D" else 0
+                c.unet_cross_attn[i] = 1 if u["down_block_types"][i].startswith("CrossAttnDownBlock2D") else 0
+            c.unet_music = 1 if u.get("music") else 0
             c.unet_layers_per_block = u["layers_per_block"]
             c.unet_in_channels = u["in_channels"]
             c.unet_out_channels = u["out_channels"]
@@ -191,23 +203,38 @@ class Engine:
     def _f32(self, t):
         return t.detach().to(device=self.device, dtype=torch.float32).contiguous()
 
-    def unet_forward(self, sample, timestep, encoder_hidden_states, encoder_attention_mask=None):
+    def _u8(self, m):
+        return m.to(self.device).to(torch.uint8).contiguous() if m is not None else None
+
+    def unet_forward(self, sample, timestep, encoder_hidden_states, encoder_attention_mask=None, beat_features=None,
+                     chord_features=None, beat_attention_mask=None, chord_attention_mask=None):
+        """UNet2DConditionModel.forward; with beat / chord features, UNet2DConditionModelMusic.forward (Music configs only)"""
         x = self._f32(sample)
         enc = self._f32(encoder_hidden_states)
         B2, L = enc.shape[0], enc.shape[1]
-        mask = None
-        if encoder_attention_mask is not None:
-            mask = encoder_attention_mask.to(self.device).to(torch.uint8).contiguous()
+        mask = self._u8(encoder_attention_mask)
         out = torch.empty_like(x)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+        music = bool(self.unet_cfg.get("music"))
+        if music != (beat_features is not None and chord_features is not None):
+            raise ValueError("beat_features / chord_features are required by (and only by) a Music UNet config")
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.tango_engine_unet_forward(
-                self._h, C.c_void_p(x.data_ptr()), int(timestep), C.c_void_p(enc.data_ptr()),
-                C.c_void_p(mask.data_ptr()) if mask is not None else None, C.c_void_p(out.data_ptr()), B2, L,
-                _stream_ptr()), "unet_forward")
+            if music:
+                beat, chord = self._f32(beat_features), self._f32(chord_features)
+                bm, cm = self._u8(beat_attention_mask), self._u8(chord_attention_mask)
+                if beat.shape[0] != B2 or chord.shape[0] != B2:
+                    raise ValueError("beat / chord features must have the batch of encoder_hidden_states")
+                _lib.check(self.lib.tango_engine_unet_forward_music(
+                    self._h, p(x), int(timestep), p(enc), p(mask), p(beat), p(bm), p(chord), p(cm), p(out), B2, L, beat.shape[1],
+                    chord.shape[1], _stream_ptr()), "unet_forward_music")
+            else:
+                _lib.check(self.lib.tango_engine_unet_forward(self._h, p(x), int(timestep), p(enc), p(mask), p(out), B2, L,
+                                                              _stream_ptr()), "unet_forward")
         return out
 
     def denoise(self, latents, prompt_embeds, prompt_mask, timesteps, coef, guidance_scale, prediction_type="v_prediction",
-                rule="ddpm", clip_sample=False, clip_sample_range=1.0, noise=None, seed=0, sample_offset=0, use_graph=True):
+                rule="ddpm", clip_sample=False, clip_sample_range=1.0, noise=None, seed=0, sample_offset=0, use_graph=True,
+                beat_embeds=None, beat_mask=None, chord_embeds=None, chord_mask=None):
         """In-place denoise of `latents` [B,8,256,16] (fp32 cuda).  `timesteps` int64 [N] and `coef`
         float32 [N,8] are host tables from tango_amd.scheduler."""
         assert latents.is_cuda and latents.dtype == torch.float32 and latents.is_contiguous()
@@ -237,6 +264,17 @@ class Engine:
         a.seed = int(seed)
         a.sample_offset = int(sample_offset)
         a.use_graph = 1 if use_graph else 0
+        keep = []
+        if self.unet_cfg.get("music"):
+            if beat_embeds is None or chord_embeds is None:
+                raise ValueError("a Music UNet needs beat_embeds and chord_embeds")
+            be, ce = self._f32(beat_embeds), self._f32(chord_embeds)
+            bm, cm = self._u8(beat_mask), self._u8(chord_mask)
+            keep = [be, ce, bm, cm]
+            if be.shape[0] != enc.shape[0] or ce.shape[0] != enc.shape[0]:
+                raise ValueError("beat / chord embeddings must have the batch of prompt_embeds")
+            a.beat_embeds, a.beat_len, a.beat_mask = be.data_ptr(), be.shape[1], bm.data_ptr() if bm is not None else None
+            a.chord_embeds, a.chord_len, a.chord_mask = ce.data_ptr(), ce.shape[1], cm.data_ptr() if cm is not None else None
         expect = 2 * a.batch if guidance_scale > 1.0 else a.batch
         if enc.shape[0] != expect:
             raise ValueError("prompt_embeds batch %d != %d" % (enc.shape[0], expect))

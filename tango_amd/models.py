@@ -63,8 +63,10 @@ class _UNetHandle:
         self.in_channels = cfg["in_channels"]
         self._engine = engine
 
-    def __call__(self, sample, timestep, encoder_hidden_states=None, encoder_attention_mask=None, **_):
-        out = self._engine.unet_forward(sample, int(timestep), encoder_hidden_states, encoder_attention_mask)
+    def __call__(self, sample, timestep, encoder_hidden_states=None, encoder_attention_mask=None, beat_features=None,
+                 chord_features=None, beat_attention_mask=None, chord_attention_mask=None, **_):
+        out = self._engine.unet_forward(sample, int(timestep), encoder_hidden_states, encoder_attention_mask, beat_features,
+                                        chord_features, beat_attention_mask, chord_attention_mask)
         return SimpleNamespace(sample=out)
 
 
@@ -236,3 +238,52 @@ class AudioDiffusion:
             pe = pe.repeat_interleave(num_samples_per_prompt, 0)
             pm = pm.repeat_interleave(num_samples_per_prompt, 0)
         return self.inference_from_embeddings(pe.float(), pm, inference_scheduler, num_steps, guidance_scale)
+
+
+class MusicAudioDiffusion(AudioDiffusion):
+    """Inference side of Mustango's `MusicAudioDiffusion` (mustango/models.py:312-740) on the engine: the UNet is
+    UNet2DConditionModelMusic (mustango/configs/music_diffusion_model_config.json -- every cross-attention site attends to the
+    text, then the beat, then the chord embeddings) and the loop of mustango/models.py:563-598 runs as the same captured
+    hipGraph step with three condition tensors bound.
+
+    What stays with the caller, exactly like the T5 encoder of `AudioDiffusion`: the symbolic front-end that turns beat / chord
+    annotations into embeddings -- `beat_tokenizer`, `chord_tokenizer`, `Beat_Embedding`, `Chord_Embedding`,
+    `Fundamental_Music_Embedding`, `Music_PositionalEncoding` (mustango/layers/layers.py, mustango/models.py:376-388,433-467):
+    small trainable torch modules whose outputs ([B, 50, 1024] beats, [B, 20, 1024] chords and their masks,
+    `encode_beats_classifier_free` / `encode_chords_classifier_free` ordered [uncond; cond]) are this class's inputs."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        if not self.unet_config.get("music"):
+            raise ValueError("MusicAudioDiffusion needs a UNet config with *Music blocks (mustango/configs/music_diffusion_model_config.json)")
+
+    @torch.no_grad()
+    def inference_from_embeddings(self, prompt_embeds, boolean_prompt_mask, inference_scheduler, num_steps=20, guidance_scale=3,
+                                  latents=None, noise=None, seed=None, sample_offset=0, *, encoded_beats=None, beat_mask=None,
+                                  encoded_chords=None, chord_mask=None):
+        """mustango/models.py:540-598 given the three encoder outputs ([uncond; cond] when guidance > 1)."""
+        if encoded_beats is None or encoded_chords is None:
+            raise ValueError("encoded_beats and encoded_chords are required (mustango/models.py:548-550)")
+        cfg_on = guidance_scale > 1.0
+        B = prompt_embeds.shape[0] // 2 if cfg_on else prompt_embeds.shape[0]
+        inference_scheduler.set_timesteps(num_steps, device=self.device)
+        if latents is None:
+            latents = self.prepare_latents(B, inference_scheduler, self.unet.config.in_channels, torch.float32, self.device)
+        latents = latents.to(self.device, torch.float32).contiguous().clone()
+        if boolean_prompt_mask is None:
+            boolean_prompt_mask = torch.ones(prompt_embeds.shape[:2], dtype=torch.bool, device=prompt_embeds.device)
+        pe, pm = self._pad_text(prompt_embeds.to(self.device), boolean_prompt_mask.to(self.device))
+        c = inference_scheduler.config
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.seed is None else (int(self.seed) << 20) + self._calls
+        self._calls += 1
+        self.engine.denoise(latents, pe, pm, inference_scheduler.timesteps.cpu().numpy(), inference_scheduler.coef_table(), guidance_scale,
+                            prediction_type=c.prediction_type, rule=inference_scheduler.rule, clip_sample=c.clip_sample,
+                            clip_sample_range=getattr(c, "clip_sample_range", 1.0), noise=noise, seed=seed,
+                            sample_offset=sample_offset, use_graph=self.use_graph, beat_embeds=encoded_beats, beat_mask=beat_mask,
+                            chord_embeds=encoded_chords, chord_mask=chord_mask)
+        return latents
+
+    def inference(self, *a, **k):
+        raise NotImplementedError("strings / beat and chord annotations are encoded by the caller's Mustango front-end modules; "
+                                  "pass their outputs to inference_from_embeddings()")

@@ -65,7 +65,14 @@ def _transformer(out, p, c, cross):
 
 
 def unet_param_shapes(cfg: dict, prefix: str = "") -> Shapes:
-    """All UNet tensors for a Tango-style config (686 tensors for configs/diffusion_model_config.json)."""
+    """All UNet tensors for a Tango-style config (686 tensors for configs/diffusion_model_config.json; 1518 for Mustango's
+    mustango/configs/music_diffusion_model_config.json, whose *Music blocks carry `attentions2` / `attentions3` next to
+    `attentions` at every cross-attention site)."""
+    music = any(str(t).endswith("Music") for t in list(cfg["down_block_types"]) + list(cfg["up_block_types"]))
+
+    def _site(out, p, j, c, cross):
+        for name in (("attentions", "attentions2", "attentions3") if music else ("attentions",)):
+            _transformer(out, f"{p}.{name}.{j}", c, cross)
     ch = list(cfg["block_out_channels"])
     cross = cfg["cross_attention_dim"]
     lpb = cfg.get("layers_per_block", 2)
@@ -83,15 +90,15 @@ def unet_param_shapes(cfg: dict, prefix: str = "") -> Shapes:
         for j in range(lpb):
             cin = c_prev if j == 0 else ch[i]
             _resnet(out, f"{P}down_blocks.{i}.resnets.{j}", cin, ch[i], temb)
-            if bt == "CrossAttnDownBlock2D":
-                _transformer(out, f"{P}down_blocks.{i}.attentions.{j}", ch[i], cross)
+            if bt in ("CrossAttnDownBlock2D", "CrossAttnDownBlock2DMusic"):
+                _site(out, f"{P}down_blocks.{i}", j, ch[i], cross)
         if i != len(ch) - 1:
             out[f"{P}down_blocks.{i}.downsamplers.0.conv.weight"] = (ch[i], ch[i], 3, 3)
             out[f"{P}down_blocks.{i}.downsamplers.0.conv.bias"] = (ch[i],)
         c_prev = ch[i]
     cm = ch[-1]
     _resnet(out, P + "mid_block.resnets.0", cm, cm, temb)
-    _transformer(out, P + "mid_block.attentions.0", cm, cross)
+    _site(out, P + "mid_block", 0, cm, cross)
     _resnet(out, P + "mid_block.resnets.1", cm, cm, temb)
     rch = list(reversed(ch))
     prev_out = rch[0]
@@ -102,8 +109,8 @@ def unet_param_shapes(cfg: dict, prefix: str = "") -> Shapes:
             skip = inc if j == lpb else outc
             rin = prev_out if j == 0 else outc
             _resnet(out, f"{P}up_blocks.{i}.resnets.{j}", rin + skip, outc, temb)
-            if bt == "CrossAttnUpBlock2D":
-                _transformer(out, f"{P}up_blocks.{i}.attentions.{j}", outc, cross)
+            if bt in ("CrossAttnUpBlock2D", "CrossAttnUpBlock2DMusic"):
+                _site(out, f"{P}up_blocks.{i}", j, outc, cross)
         if i != len(ch) - 1:
             out[f"{P}up_blocks.{i}.upsamplers.0.conv.weight"] = (outc, outc, 3, 3)
             out[f"{P}up_blocks.{i}.upsamplers.0.conv.bias"] = (outc,)

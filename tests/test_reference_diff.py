@@ -61,3 +61,40 @@ def test_scheduler_step_matches_fork_bitwise():
         ra = a.step(v, t, x, generator=torch.Generator().manual_seed(9)).prev_sample
         rb = b.step(v, t, x, generator=torch.Generator().manual_seed(9))
         assert torch.equal(ra, rb)
+
+
+def _music_ref(cfgo):
+    import json
+    import os
+    cfg = json.load(open(os.path.join(R.REF, "mustango", "configs", "music_diffusion_model_config.json")))
+    cfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
+    cfg.update({k: cfgo[k] for k in ("block_out_channels", "attention_head_dim", "cross_attention_dim")})
+    return cfg
+
+
+from oracle.make_golden import music_inputs  # noqa: E402
+
+
+def test_music_unet_inventory_and_forward_match_mustango():
+    """Mustango's UNet2DConditionModelMusic (unet_2d_condition_music.py:536-757): parameter inventory at the real config and the
+    oracle's three-transformers-per-site forward against the imported class (tiny widths)"""
+    with torch.device("meta"):
+        big = R.unet_music_cls()(**_music_ref(O.UNET_CONFIG_MUSIC))
+    ref = {k: tuple(v.shape) for k, v in big.state_dict().items()}
+    mine = {k: tuple(v) for k, v in W.unet_param_shapes(O.UNET_CONFIG_MUSIC).items()}
+    assert ref == mine and len(mine) == 1518
+    cfgo = O.UNET_CONFIG_MUSIC_TINY
+    torch.manual_seed(0)
+    unet = R.unet_music_cls()(**_music_ref(cfgo)).eval()
+    sd = W.synth_state_dict(W.unet_param_shapes(cfgo), 1234)
+    unet.load_state_dict(sd)
+    x, enc, beat, chord, em, bm, cm = music_inputs(cfgo, 4, 3)
+    want = unet(x, torch.tensor(801), encoder_hidden_states=enc, beat_features=beat, chord_features=chord, encoder_attention_mask=em,
+                beat_attention_mask=bm, chord_attention_mask=cm).sample
+    got = O.unet_forward(sd, cfgo, x, 801, enc, em, "", beat_features=beat, chord_features=chord, beat_attention_mask=bm,
+                         chord_attention_mask=cm)
+    err = ((got - want).abs().max() / want.abs().max()).item()
+    assert err <= 2e-5, err
+    plain = O.unet_forward({k: v for k, v in sd.items()}, dict(cfgo, down_block_types=O.UNET_CONFIG_LARGE["down_block_types"],
+                                                              up_block_types=O.UNET_CONFIG_LARGE["up_block_types"]), x, 801, enc, em, "")
+    assert (plain - want).abs().max().item() > 1e-2, "the beat / chord transformers must matter"
