@@ -7,7 +7,8 @@
 One "step" = one full pass of the hot path over one batch per GPU: the CFG denoise loop
 (`--denoise-steps` UNet+scheduler iterations, default 200) -> mel-VAE decode -> HiFi-GAN -> int16, for
 `--batch` (default 32) synthetic 64-token prompts per GPU (BASELINE config 3: Tango-full, 200 steps,
-batch 32, guidance 3).  Inputs (text-encoder outputs, initial latents) are resident in HBM when the timed
+batch 32, guidance 3).  Other BASELINE configs: `--batch 1 --denoise-steps 100` (config 2), `--xl --dtype bf16 --fp8-attn
+--batch 8` (config 5's per-GPU shard); `config.workload` in the JSON line names what actually ran.  Inputs (text-encoder outputs, initial latents) are resident in HBM when the timed
 region starts; weights are seeded synthetic tensors of the real architecture (no checkpoint offline).
 Metric: audio-seconds generated per wall-second, whole job (all GPUs).  Weak scaling: per-GPU batch fixed.
 """
@@ -37,15 +38,46 @@ PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROAR
 #: the committed evidence file named in profiles/hbm_traffic.json and the JSON line names that file next to it.
 
 
-def hbm_traffic(batch, dtype, xl):
+def hbm_traffic(batch, dtype, xl, fp8=False):
+    """(bytes per denoise-step launch, evidence file) for THIS configuration, or (None, None): a record only counts when it was
+    taken on the tree being benchmarked -- profiles/hbm_traffic.json names the library build it measured ("lib_sha16" = first 16
+    hex digits of sha256(libtango_hip.so's kernel sources), tools/final_profiles.sh) and a stale record is not reported."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
     except (OSError, ValueError):
         return None, None
+    cur = kernel_source_sha16()
     for r in rec.get("records", []):
-        if r.get("batch") == batch and r.get("dtype") == dtype and bool(r.get("xl", False)) == bool(xl):
+        if (r.get("batch") == batch and r.get("dtype") == dtype and bool(r.get("xl", False)) == bool(xl)
+                and bool(r.get("fp8_attn", False)) == bool(fp8) and r.get("src_sha16") == cur):
             return float(r["bytes_per_step"]), r.get("source")
     return None, None
+
+
+def kernel_source_sha16():
+    """identity of the kernel sources the library was built from (csrc/*.hip, *.h in name order)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "tango_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def workload_name(args):
+    """which BASELINE.json config (if any) this invocation is: the label must say what RAN, not what the default is"""
+    std = abs(args.guidance - 3.0) < 1e-9 and args.text_len == 64
+    if std and not args.xl and not args.fp8_attn and args.batch == 32 and args.denoise_steps == 200 and args.dtype == "fp16":
+        return "BASELINE config 3"
+    if std and not args.xl and not args.fp8_attn and args.batch == 1 and args.denoise_steps == 100 and args.dtype == "fp16":
+        return "BASELINE config 2"
+    if std and not args.xl and not args.fp8_attn and args.batch == 32 and args.denoise_steps == 200:
+        return "BASELINE config 4's per-GPU shard (256 prompts / 8 GPUs) == config 3's shape, %s" % args.dtype
+    if std and args.xl and args.fp8_attn and args.dtype == "bf16" and args.batch == 8 and args.denoise_steps == 200:
+        return "BASELINE config 5's per-GPU shard (64 prompts / 8 GPUs)"
+    return "custom (not a BASELINE.json config)"
 
 
 def parse():
@@ -59,6 +91,7 @@ def parse():
     ap.add_argument("--text-len", type=int, default=64)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
     ap.add_argument("--xl", action="store_true", help="FLAN-T5-XL cross-attention width (2048)")
+    ap.add_argument("--fp8-attn", action="store_true", help="self-attention P.V on the fp8 MFMA (BASELINE config 5; 16-bit dtypes)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
@@ -85,7 +118,7 @@ def cpu_baseline(args, unet_cfg, vae_cfg, hifi_cfg, sched_cfg):
     # thread-count sweep on one UNet forward: torch's default (= all hardware threads) oversubscribes the memory system on
     # big hosts (round 1: 8.25 s/step at 128 threads vs 2.7 s at 8) -- report the BEST the host can do, with its core count
     ncpu = os.cpu_count() or 1
-    cands = sorted({c for c in (16, 32, 64, ncpu) if 1 <= c <= ncpu})
+    cands = sorted({c for c in (8, 16, 32, 64, ncpu) if 1 <= c <= ncpu})
     sweep = {}
     with torch.no_grad():
         O.unet_forward(usd, unet_cfg, torch.cat([lat] * 2), 999, enc, mask, prefix="unet.")   # page-in / thread-pool warm-up
@@ -135,7 +168,7 @@ def main():
     from tango_amd.tango import Tango
 
     unet_cfg = UNET_CONFIG_XL if args.xl else UNET_CONFIG_LARGE
-    model = AudioDiffusion(unet_config=unet_cfg, dtype=args.dtype, device=device)
+    model = AudioDiffusion(unet_config=unet_cfg, dtype=args.dtype, device=device, attn_fp8=args.fp8_attn)
     model.engine.load_synthetic(args.seed)
     model.use_graph = not args.no_graph
     vae = AutoencoderKL(ddconfig=dict(VAE_CONFIG, attn_resolutions=[]), embed_dim=8, scale_factor=VAE_CONFIG["scale_factor"],
@@ -200,16 +233,17 @@ def main():
         # roofline of the dominant launch = one hipGraph replay of the UNet step (MFMA-bound):
         # algorithmic 1606.36 GFLOP per (prompt, step) x B prompts per launch / measured launch duration
         ach = GFLOP_UNET_PER_PROMPT_STEP * B / per_step_ms   # GFLOP / ms == TFLOP/s
-        traffic, traffic_src = hbm_traffic(B, args.dtype, args.xl)
+        traffic, traffic_src = hbm_traffic(B, args.dtype, args.xl, args.fp8_attn)
         out = {
             "metric": "audio-seconds generated/sec, Tango-full %d-step, batch=%d, guidance=%g" % (args.denoise_steps, B, args.guidance),
             "value": audio_s / dt, "unit": "audio-seconds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic (seeded random weights of the real architecture; N(0,1) text embeddings)",
-            "config": {"workload": "BASELINE config 3: Tango-full%s UNet (866M) %d-step DDPM CFG=%g denoise + mel-VAE decode + "
-                                   "HiFi-GAN, %d prompts/GPU x %d tokens" % (" XL" if args.xl else "", args.denoise_steps, args.guidance, B, L),
+            "config": {"workload": "%s: Tango-full%s UNet (866M) %d-step DDPM CFG=%g denoise%s + mel-VAE decode + "
+                                   "HiFi-GAN, %d prompts/GPU x %d tokens" % (workload_name(args), " XL" if args.xl else "", args.denoise_steps,
+                                                                             args.guidance, " with fp8 P.V self-attention" if args.fp8_attn else "", B, L),
                        "global_batch": Bg, "text_len": L, "denoise_steps": args.denoise_steps, "parallelism": "dp%d" % world,
-                       "hipgraph": not args.no_graph},
+                       "hipgraph": not args.no_graph, "fp8_attention": bool(args.fp8_attn), "kernel_src_sha16": kernel_source_sha16()},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                          "frac": ach / PEAK_TFLOPS[args.dtype],
                          "traffic": traffic, "traffic_source": traffic_src,

@@ -106,6 +106,10 @@ typedef struct tango_config {
    * embeddings), `attentions3` (chord embeddings), unet_2d_blocks.py:1199-1260,715-757,2372-2436.  All three conditions have
    * width unet_cross_dim. */
   int32_t unet_music;
+  /* BASELINE config 5 ("bf16 + fp8 MFMA attention"): != 0 runs the P.V product of the UNet's self-attention sites on
+   * v_mfma_f32_16x16x32_fp8_fp8 (P and V as OCP e4m3, fp32 accumulation, fp32 softmax statistics; Q.K^T stays in `dtype`).
+   * 16-bit engines only.  Measured deviation: DESIGN.md section 3. */
+  int32_t unet_attn_fp8;
 } tango_config_t;
 
 typedef struct tango_denoise_args {
@@ -218,6 +222,9 @@ int tango_op_layernorm(int dtype, const float* x, const float* gamma, const floa
                        void* stream);
 int tango_op_attention(int dtype, const float* q, const float* k, const float* v, const float* bias, float* out, int B, int heads,
                        int Sq, int Skv, float scale, void* stream);
+/* as tango_op_attention; flags bit 0: P.V on the fp8 MFMA (16-bit dtypes, no bias, Skv % 64 == 0) */
+int tango_op_attention_ex(int dtype, const float* q, const float* k, const float* v, const float* bias, float* out, int B, int heads,
+                          int Sq, int Skv, float scale, int flags, void* stream);
 int tango_op_sched_step(float* latents, const float* model_out_nchw, const float* noise, const float* coef8, int B, int C, int HW,
                         int cfg, float guidance, int pred_type, int rule, int clip, float clip_range, void* stream);
 

@@ -62,12 +62,25 @@ __device__ __forceinline__ float quad_max(float v) {
   return asm_max(__builtin_bit_cast(float, (unsigned)q[0]), __builtin_bit_cast(float, (unsigned)q[1]));
 }
 
+// four floats -> four OCP e4m3 bytes in one dword (v_cvt_pk_fp8_f32 x2, round to nearest even)
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+}
+
 // NW waves per workgroup share one K / V^T tile stream: the L2 -> LDS fill per workgroup is fixed (the whole K and V of
 // the (batch, head)), so the fill bytes per MFMA flop scale with 1 / (NW * QB).
 // PB: additive per-(head, query, key) bias shared by the batch (T5 relative position bias); implies MASKED.
-template <typename T, int QB, bool MASKED, int NW, int MINW, bool PB = false>
+// F8 (round 3; BASELINE config 5 "bf16 + fp8 MFMA attention"): the P.V product runs on v_mfma_f32_16x16x32_fp8_fp8 -- P and V as
+// OCP e4m3, fp32 accumulation and fp32 softmax statistics; Q.K^T stays in T (three mantissa bits on the logits would move the
+// softmax weights by 5-20 %).  P is carried as 2^8 P (so the e4m3 subnormal floor sits at 7.6e-6 instead of 2e-3 of the row
+// maximum -- with 4096 keys most weights are far below 2e-3); the factor cancels in O = (P V) / sum(P) because the row sum is
+// taken of the same scaled values.  V^T is converted while its tile is staged (clamped to the e4m3 range, +-448).
+template <typename T, int QB, bool MASKED, int NW, int MINW, bool PB = false, bool F8 = false>
 __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p) {
   static_assert(!PB || MASKED, "position bias rides on the masked path");
+  static_assert(!F8 || (sizeof(T) == 2 && !PB), "fp8 P.V: 16-bit engines, no position bias");
   constexpr int NTH = NW * 64;
   constexpr int EPV = 16 / (int)sizeof(T);
   constexpr int D = 64, KVT = 64;
@@ -156,7 +169,21 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
       const int id = tid + i * NTH;
       const int row = id / PPR, pc = id % PPR;
       if (NPIECE % NTH != 0 && id >= NPIECE) continue;
-      if (HALF) {
+      if (F8) {
+        *(u32x4*)(Ks + row * LDSR + ((pc ^ (row & 7)) * 16)) = kreg[i];
+        // V^T as e4m3, 64-byte rows of 8 x 8-byte slots: slot 4j + gg holds [kv 32j + 4gg .. +3 | kv 32j + 16 + 4gg .. +3] (the
+        // key order in which a lane's P^T fragment presents them); slot ^= 2 * ((row >> 2) & 3) spreads the 16 rows x 2 lane groups
+        // of a ds_read_b64 half-wave over all 64 banks
+        T e[8];
+        __builtin_memcpy(e, &vreg[i], 16);
+        float f[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) f[u] = __builtin_amdgcn_fmed3f(to_f(e[u]), -448.f, 448.f);
+        const int j = pc >> 2, hi = (pc >> 1) & 1, gg0 = (pc & 1) * 2, sw = 2 * ((row >> 2) & 3);
+        unsigned char* vr = Vs + row * 64;
+        *(unsigned*)(vr + (((4 * j + gg0) ^ sw) * 8) + hi * 4) = pack_fp8x4(f[0], f[1], f[2], f[3]);
+        *(unsigned*)(vr + (((4 * j + gg0 + 1) ^ sw) * 8) + hi * 4) = pack_fp8x4(f[4], f[5], f[6], f[7]);
+      } else if (HALF) {
         *(u32x4*)(Ks + row * LDSR + ((pc ^ (row & 7)) * 16)) = kreg[i];
         // V^T: piece pc holds kv = 8pc..8pc+7 of this 64-tile: 32-block j = pc>>2, c = (pc&3)*8 + e.
         // column c = 16*hi + 4*gg + r is stored at c' = 8*gg + 4*hi + r (so [hi=0 | hi=1] of one gg are adjacent)
@@ -251,12 +278,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
         for (int db = 0; db < 4; ++db) oacc[qb][db] *= alpha;
       }
       float rs = 0.f;
+      const float moff = F8 ? mnew - 8.f : mnew;         // F8: P is carried as 2^8 P (<= 256 < 448 = e4m3 max); cancels in O / l
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = MASKED ? __builtin_amdgcn_exp2f(sacc[qb][kb][r] - mnew)
-                                  : __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qb][kb][r], sc2, -mnew));
+          const float pv = MASKED ? __builtin_amdgcn_exp2f(sacc[qb][kb][r] - moff)
+                                  : __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qb][kb][r], sc2, -moff));
           sacc[qb][kb][r] = pv;
           rs += pv;
         }
@@ -264,7 +292,25 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
     }
 
     // ---- O^T += V^T P^T ----
-    if constexpr (HALF) {
+    if constexpr (F8) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        long pf8[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          const unsigned lo = pack_fp8x4(sacc[qb][2 * j][0], sacc[qb][2 * j][1], sacc[qb][2 * j][2], sacc[qb][2 * j][3]);
+          const unsigned hh = pack_fp8x4(sacc[qb][2 * j + 1][0], sacc[qb][2 * j + 1][1], sacc[qb][2 * j + 1][2], sacc[qb][2 * j + 1][3]);
+          pf8[qb] = (long)(((unsigned long long)hh << 32) | lo);
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const int row = db * 16 + l15;
+          const long vf8 = *(const long*)(Vs + row * 64 + (((4 * j + g) ^ (2 * ((row >> 2) & 3))) * 8));
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(vf8, pf8[qb], oacc[qb][db], 0, 0, 0);
+        }
+      }
+    } else if constexpr (HALF) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         u32x4 pf[QB];
@@ -344,6 +390,7 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
       (p.ldo * (int64_t)sizeof(T)) % 8)
     TANGO_FAIL("attention: ld alignment");
   const bool masked = p.bias != nullptr || (p.Skv % 64) != 0;
+  if (p.fp8_pv && sizeof(T) != 2) TANGO_FAIL("attention: fp8 P.V needs a 16-bit engine (Q.K^T stays in the engine dtype)");
   if (p.pos_bias) {   // text-encoder self-attention (short sequences): one query block per wave
     dim3 grid((unsigned)((p.Sq + 63) / 64), (unsigned)p.heads, (unsigned)p.B);
     hipLaunchKernelGGL((attn_kernel<T, 1, true, 4, 3, true>), grid, dim3(256), 0, s, p);
@@ -358,12 +405,18 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
     constexpr int QB = 2;
     dim3 grid((unsigned)((p.Sq + 64 * QB - 1) / (64 * QB)), (unsigned)p.heads, (unsigned)p.B);
     if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true, 4, 3>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
+    else if constexpr (sizeof(T) == 2) {
+      if (p.fp8_pv) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
+    } else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
   } else {
     constexpr int QB = 1;
     dim3 grid((unsigned)((p.Sq + 64 * QB - 1) / (64 * QB)), (unsigned)p.heads, (unsigned)p.B);
     if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true, 4, 3>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
+    else if constexpr (sizeof(T) == 2) {
+      if (p.fp8_pv) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
+    } else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
   }
   TANGO_HIP(hipGetLastError());
   return 0;

@@ -167,8 +167,9 @@ struct Builder {
   }
 
   void attention(const TView& q, const TView& k, const void* vt, int64_t ldvt, const TView& o, const float* bias, int B, int heads,
-                 int Sq, int Skv, float scale = 0.125f, const float* pos_bias = nullptr) {
+                 int Sq, int Skv, float scale = 0.125f, const float* pos_bias = nullptr, bool fp8_pv = false) {
     AttnParams p;
+    p.fp8_pv = fp8_pv ? 1 : 0;
     p.q = q.p; p.ldq = q.ld; p.k = k.p; p.ldk = k.ld; p.vt = vt; p.ldvt = ldvt; p.o = o.p; p.ldo = o.ld;
     p.bias = bias; p.pos_bias = pos_bias; p.B = B; p.heads = heads; p.Sq = Sq; p.Skv = Skv; p.scale = scale;
     const int d = dt;
@@ -257,7 +258,10 @@ struct Builder {
     GOpt nb; nb.use_bias = false;
     { GOpt o = nb; o.ln = &w.ln1; o.vt = vt; o.vt_n0 = 2 * C; o.vt_S = HW; o.vt_ld = HW; linear(h, rows, w.qkv, qkv, o); }
     TView a = alloc(rows, C);
-    attention(slice(qkv, 0, C, esz), slice(qkv, C, C, esz), vt, HW, a, nullptr, B, w.heads, HW, HW);
+    // self-attention; `unet_attn_fp8` (BASELINE config 5): P.V on the fp8 MFMA at the sites that dominate the attention time
+    // (unmasked, Skv a multiple of 64); cross-attention (64 text tokens, masked) stays in the engine dtype
+    attention(slice(qkv, 0, C, esz), slice(qkv, C, C, esz), vt, HW, a, nullptr, B, w.heads, HW, HW, 0.125f, nullptr,
+              E.cfg.unet_attn_fp8 != 0 && dt != DT_F32 && HW % 64 == 0);
     TView h1 = alloc(rows, C);
     { GOpt o; o.residual = &h; linear(a, rows, w.o1, h1, o); }
     TView q = slice(qkv, 0, C, esz);   // reuse the qkv buffer for the cross-attention query
@@ -690,6 +694,7 @@ void Engine::build_voc_weights() {
 int Engine::init() {
   if (dt != DT_F32 && dt != DT_F16 && dt != DT_BF16) TANGO_FAIL("engine: bad dtype");
   TANGO_TRY(gemm_init());
+  if (cfg.unet_attn_fp8 && dt == DT_F32) TANGO_FAIL("engine: unet_attn_fp8 needs a 16-bit engine dtype (bf16 / fp16)");
   if (cfg.unet_levels > 0) {
     for (int i = 0; i < cfg.unet_levels; ++i)
       if (cfg.unet_channels[i] != cfg.unet_heads[i] * 64) TANGO_FAIL("engine: UNet channels must equal heads * 64 (head_dim 64)");

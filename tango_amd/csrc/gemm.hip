@@ -17,6 +17,7 @@
 
 #include "common.h"
 #include "gemm_device.h"
+#include "tuning.h"
 
 namespace tango {
 
@@ -268,8 +269,25 @@ static int launch_cfg(const GemmParams& p, hipStream_t s) {
   return 0;
 }
 
+// Small-M linears (B = 1: M = 8192 / 2048 / 512 rows at levels 0 / 1 / 2; B = 8's level 2): the 128-row tilings leave most of the
+// 256 CUs idle and the round-1 answer -- split-K into fp32 partials + a reduce launch -- costs a second kernel and a round trip
+// per op (~22 us for a 1.7-GFLOP GEMM, profiles/r3_c1_unet_step_per_op_fp16_b1.txt).  64 x 64 tiles fill the chip with ONE
+// launch when K is short enough that a workgroup's serial k-loop stays a few microseconds.
+static bool small_tile_linear(const GemmParams& p, int esz) {
+  if (tuning().no_small_tile || p.mode != GATHER_1D || p.epi != EPI_NONE || p.batch != 1 || p.splitk > 1 || p.bias_rows) return false;
+  if (!(p.taps == 1 && p.rows_pb == p.M && p.in_mul == 1 && p.in_off == 0 && p.out_mul == 1 && p.out_off == 0 && p.Lin >= p.M)) return false;
+  if (p.N % 64 != 0 || (p.Cin * esz) % 128 != 0 || p.K > 2560) return false;
+  const int bn = (p.N % 160 == 0) ? 160 : 128;
+  const long big = (long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
+  const long small = (long)((p.M + 63) / 64) * (p.N / 64);
+  return big < 192 && small >= 96;
+}
+
 template <typename T, int BKB, int MODE>
 static int launch_tile(const GemmParams& p, hipStream_t s) {
+  if constexpr (MODE == MODE_LINEAR && BKB == 128) {
+    if (small_tile_linear(p, (int)sizeof(T))) return launch_cfg<T, 64, 64, BKB, 2, 2, MODE>(p, s);
+  }
   if (p.epi == EPI_GEGLU) {
     if (p.N % 32 != 0) TANGO_FAIL("GEGLU gemm needs N % 32 == 0");
     return launch_cfg<T, 128, 128, BKB, 2, 2, MODE>(p, s);
@@ -319,6 +337,7 @@ int gemm_pick_splitk(int dtype, const GemmParams& p) {
   if (p.mode == GATHER_1D && !(p.taps == 1 && p.rows_pb == p.M && p.in_mul == 1 && p.in_off == 0 && p.out_mul == 1 && p.out_off == 0))
     return 1;
   if (linear_stream_ok(dtype, p)) return 1;
+  if (small_tile_linear(p, dtype == DT_F32 ? 4 : 2)) return 1;      // one launch of 64 x 64 tiles instead (launch_tile)
   {
     const int sw = conv_wide_pick_splitk(dtype, p);    // e.g. 64 tiles of 256 x 320 -> 4 splits = one workgroup per CU
     // (linears: measured at M = 4096 -- 64 tiles x 4 splits -- the wide kernel is no faster than the 4-wave tiles' split-K,

@@ -386,6 +386,7 @@ bool linear_stream_ok(int dtype, const GemmParams& p) {
   if (p.epi != EPI_NONE && p.epi != EPI_GEGLU && p.epi != EPI_VT) return false;
   if (p.glu_tanh) return false;                     // the streaming epilogue implements the exact-erf gate only
   if (p.M < 4096) return false;                     // too few row groups to feed 256 CUs
+  if (tuning().stream_min_m_big && !p.ln_fold && p.M < 32768) return false;   // round-3 A/B: mid-size plain linears on the tile GEMMs
   int tn;
   if (rowb == 640) tn = 10;
   else if (rowb == 1280) tn = 5;

@@ -330,6 +330,11 @@ int tango_op_layernorm(int dt, const float* x, const float* gamma, const float* 
 
 int tango_op_attention(int dt, const float* q, const float* k, const float* v, const float* bias, float* out, int B, int heads,
                        int Sq, int Skv, float scale, void* stream) {
+  return tango_op_attention_ex(dt, q, k, v, bias, out, B, heads, Sq, Skv, scale, 0, stream);
+}
+
+int tango_op_attention_ex(int dt, const float* q, const float* k, const float* v, const float* bias, float* out, int B, int heads,
+                          int Sq, int Skv, float scale, int flags, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const size_t esz = dtype_size(dt);
   Scratch sc;
@@ -349,6 +354,10 @@ int tango_op_attention(int dt, const float* q, const float* k, const float* v, c
   AttnParams p;
   p.q = qt; p.ldq = C; p.k = kt; p.ldk = C; p.vt = vtt; p.ldvt = ldvt; p.o = ot; p.ldo = C; p.bias = bias;
   p.B = B; p.heads = heads; p.Sq = Sq; p.Skv = Skv; p.scale = scale;
+  if (flags & 1) {
+    if (bias || Skv % 64 != 0) TANGO_FAIL("op_attention_ex: the fp8 P.V path takes unmasked problems with Skv % 64 == 0");
+    p.fp8_pv = 1;
+  }
   TANGO_TRY(launch_attention(dt, p, s));
   TANGO_TRY(to_f32(dt, ot, C, out, (int64_t)B * Sq, C, s));
   TANGO_HIP(hipStreamSynchronize(s));

@@ -65,7 +65,7 @@ class Engine:
 
     def __init__(self, unet: Optional[dict] = None, vae: Optional[dict] = None, hifigan: Optional[dict] = None,
                  dtype: str = "fp16", device="cuda:0", t5: Optional[dict] = None, vae_encoder: bool = False,
-                 stft: Optional[dict] = None):
+                 stft: Optional[dict] = None, attn_fp8: bool = False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("tango_amd.Engine needs a HIP device (no CPU fallback)")
@@ -77,6 +77,9 @@ class Engine:
         self.t5_cfg = dict(t5) if t5 is not None else None
         self.vae_encoder = bool(vae_encoder) and vae is not None
         self.stft_cfg = dict(stft) if stft is not None else None
+        self.attn_fp8 = bool(attn_fp8)
+        if self.attn_fp8 and dtype in ("fp32", "float32", "f32"):
+            raise ValueError("attn_fp8 (P.V on the fp8 MFMA) needs a 16-bit engine dtype")
         c = _lib.TangoConfig()
         c.dtype = _lib.DTYPES[dtype]
         c.latent_h, c.latent_w = 256, 16
@@ -89,6 +92,7 @@ class Engine:
                 c.unet_heads[i] = u["attention_head_dim"][i]
                 c.unet_cross_attn[i] = 1 if u["down_block_types"][i].startswith("CrossAttnDownBlock2D") else 0
             c.unet_music = 1 if u.get("music") else 0
+            c.unet_attn_fp8 = 1 if attn_fp8 else 0
             c.unet_layers_per_block = u["layers_per_block"]
             c.unet_in_channels = u["in_channels"]
             c.unet_out_channels = u["out_channels"]

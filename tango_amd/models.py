@@ -73,7 +73,8 @@ class _UNetHandle:
 class AudioDiffusion:
     def __init__(self, text_encoder_name=None, scheduler_name=None, unet_model_name=None, unet_model_config_path=None,
                  snr_gamma=None, freeze_text_encoder=True, uncondition=False, *, unet_config: Optional[dict] = None,
-                 dtype: str = "fp16", device="cuda:0", text_encoder=None, tokenizer=None, bucket_text_len: bool = True):
+                 dtype: str = "fp16", device="cuda:0", text_encoder=None, tokenizer=None, bucket_text_len: bool = True,
+                 attn_fp8: bool = False):
         assert unet_model_name is None, "released Tango checkpoints take the set_from == 'random' branch (models.py:83-86)"
         if unet_config is None:
             if unet_model_config_path is None:
@@ -84,7 +85,7 @@ class AudioDiffusion:
         self.scheduler_name = scheduler_name
         self.set_from = "random"
         self.device = torch.device(device)
-        self.engine = Engine(unet=self.unet_config, dtype=dtype, device=device)
+        self.engine = Engine(unet=self.unet_config, dtype=dtype, device=device, attn_fp8=attn_fp8)
         self.unet = _UNetHandle(self.unet_config, self.engine)
         self.text_encoder = text_encoder
         self.tokenizer = tokenizer

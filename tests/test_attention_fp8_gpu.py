@@ -1,0 +1,116 @@
+"""fp8 P.V attention (BASELINE config 5: "bf16 + fp8 MFMA attention"): the self-attention sites' P.V product
+on v_mfma_f32_16x16x32_fp8_fp8 -- P (carried as 2^8 P) and V as OCP e4m3, fp32 accumulation and softmax statistics, Q.K^T in the
+engine dtype (attention.hip, template parameter F8).
+
+Two references per case:
+  * an EMULATION of exactly that arithmetic in torch (tile-wise online softmax over 64-key tiles, torch.float8_e4m3fn round trips
+    of 256 P and of clamp(V, +-448), fp32 row sums of the unquantised 256 P) -- tight: the kernel computes what it says;
+  * the exact softmax(Q K^T) V -- loose: what switching the feature on costs (three mantissa bits on P and V, averaged over keys)."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = {"fp16": 1, "bf16": 2}
+
+
+def q16(t, dtype):
+    return t.half().float() if dtype == "fp16" else t.bfloat16().float()
+
+
+def f8(t):
+    return t.to(torch.float8_e4m3fn).float()
+
+
+def emulate(qh, kh, vh, scale):
+    """[B, h, S, 64] tensors (already rounded to the engine dtype) -> O as the F8 kernel computes it"""
+    B, H, Sq, _ = qh.shape
+    Skv = kh.shape[2]
+    m = torch.full((B, H, Sq, 1), -1e30)
+    l = torch.zeros(B, H, Sq, 1)
+    o = torch.zeros(B, H, Sq, 64)
+    vq = f8(vh.clamp(-448, 448))
+    for t0 in range(0, Skv, 64):
+        s = (qh @ kh[:, :, t0:t0 + 64].transpose(-1, -2)) * scale
+        mn = torch.maximum(m, s.amax(-1, keepdim=True))
+        alpha = torch.exp(m - mn)
+        p = 256.0 * torch.exp(s - mn)
+        l = l * alpha + p.sum(-1, keepdim=True)
+        o = o * alpha + f8(p) @ vq[:, :, t0:t0 + 64]
+        m = mn
+    return o / l
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,heads,S,spread", [(2, 2, 256, 1.0), (1, 5, 4096, 1.0), (2, 3, 64, 1.0), (1, 2, 1024, 4.0), (1, 1, 4096, 0.05)])
+def test_attention_fp8_pv(lib, dtype, B, heads, S, spread):
+    """`spread` scales the logits: 4.0 = peaked rows (one or two keys carry the weight), 0.05 = flat rows -- 4096 weights of
+    ~1/4096 each, the case the 2^8 pre-scale exists for (unscaled they would all sit below e4m3's subnormal step 2^-9)"""
+    g = torch.Generator().manual_seed(S + heads)
+    C_ = heads * 64
+    q = q16(torch.randn(B, S, C_, generator=g) * spread, dtype)
+    k = q16(torch.randn(B, S, C_, generator=g), dtype)
+    v = q16(torch.randn(B, S, C_, generator=g) * 1.5 + 0.3, dtype)
+    v[0, 0, 0] = 1000.0                      # beyond the e4m3 range: clamped, not inf / NaN
+    v = q16(v, dtype)
+    qh, kh, vh = (t.view(B, S, heads, 64).transpose(1, 2) for t in (q, k, v))
+    exact = ((qh @ kh.transpose(-1, -2) * 0.125).softmax(-1) @ vh.clamp(-448, 448)).transpose(1, 2).reshape(B, S, C_)
+    emu = emulate(qh, kh, vh, 0.125).transpose(1, 2).reshape(B, S, C_)
+    out = torch.empty(B, S, C_, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    rc = lib.tango_op_attention_ex(DT[dtype], p(qd), p(kd), p(vd), None, p(out), B, heads, S, S, 0.125, 1, None)
+    assert rc == 0, lib.tango_last_error().decode()
+    out = out.cpu()
+    assert torch.isfinite(out).all()
+    scale = exact.abs().max().item()
+    e_emu = (out - emu).abs().max().item() / scale
+    e_exact = (out - exact).abs().max().item() / scale
+    rms = ((out - exact).pow(2).mean().sqrt() / exact.pow(2).mean().sqrt()).item()
+    print("fp8 P.V attention %s B=%d h=%d S=%d spread %.2f: vs emulation %.3e, vs exact softmax(QK^T)V max %.3e / rms %.3e (of the output scale)"
+          % (dtype, B, heads, S, spread, e_emu, e_exact, rms))
+    out_tol = 4e-3 if dtype == "fp16" else 1.2e-2           # the 16-bit output rounding on top of the emulated arithmetic
+    assert e_emu <= out_tol, e_emu
+    assert e_exact <= 8e-2 and rms <= 4e-2, (e_exact, rms)
+    # and the switch is really on: the 16-bit kernel on the same inputs is closer to the exact result
+    base = torch.empty(B, S, C_, device="cuda")
+    assert lib.tango_op_attention_ex(DT[dtype], p(qd), p(kd), p(vd), None, p(base), B, heads, S, S, 0.125, 0, None) == 0
+    assert (base.cpu() - exact).abs().max().item() / scale < e_exact
+
+
+def test_fp8_pv_argument_errors(lib):
+    x = torch.randn(1, 64, 64, device="cuda")
+    out = torch.empty_like(x)
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    assert lib.tango_op_attention_ex(0, p(x), p(x), p(x), None, p(out), 1, 1, 64, 64, 0.125, 1, None) != 0      # fp32 engine
+    assert b"16-bit" in lib.tango_last_error()
+    bias = torch.zeros(1, 64, device="cuda")
+    assert lib.tango_op_attention_ex(2, p(x), p(x), p(x), p(bias), p(out), 1, 1, 64, 64, 0.125, 1, None) != 0   # masked site
+    from tango_amd.engine import UNET_CONFIG_LARGE, Engine
+    with pytest.raises(ValueError):
+        Engine(unet=UNET_CONFIG_LARGE, dtype="fp32", attn_fp8=True)
+
+
+@pytest.mark.parametrize("dtype,tol", [("bf16", 1.5e-1), ("fp16", 6e-2)])
+def test_unet_forward_with_fp8_attention_tiny(dtype, tol):
+    from oracle import tango_oracle as O
+    from tango_amd import weights as W
+    from tango_amd.engine import Engine
+    cfg = O.UNET_CONFIG_TINY
+    sd = W.synth_state_dict(W.unet_param_shapes(cfg, "unet."), 1234)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 8, 256, 16, generator=g)
+    enc = torch.randn(2, 8, cfg["cross_attention_dim"], generator=g)
+    with torch.no_grad():
+        ref = O.unet_forward(sd, cfg, x, 500, enc, None, prefix="unet.")
+    outs = {}
+    for f8on in (False, True):
+        e = Engine(unet=cfg, dtype=dtype, attn_fp8=f8on)
+        e.load_synthetic(1234)
+        outs[f8on] = e.unet_forward(x.cuda(), 500, enc.cuda(), None).cpu()
+    e0 = ((outs[False] - ref).abs().max() / ref.abs().max()).item()
+    e1 = ((outs[True] - ref).abs().max() / ref.abs().max()).item()
+    print("tiny UNet %s: rel err vs oracle %.3e, with fp8 P.V attention %.3e" % (dtype, e0, e1))
+    assert e1 <= tol and not torch.equal(outs[False], outs[True])

@@ -59,9 +59,9 @@ def config1_reference():
     return _ref["c1"]
 
 
-def run_config1(dtype):
+def run_config1(dtype, attn_fp8=False):
     r = config1_reference()
-    e = Engine(unet=O.UNET_CONFIG_LARGE, dtype=dtype)
+    e = Engine(unet=O.UNET_CONFIG_LARGE, dtype=dtype, attn_fp8=attn_fp8)
     e.load_synthetic(1234)
     sch = _sched()
     sch.set_timesteps(r["N"])
@@ -118,6 +118,18 @@ def test_config1_reduced_precision_ladder(dtype, lat_tol, mel_floor, wav_floor):
     p, s = psnr(mel, r["mel"]), snr_db(wav, r["wav"])
     print("config 1 %s engine vs fp32 oracle: latents max abs err %.3e, mel PSNR %.1f dB, waveform SNR %.1f dB" % (dtype, err, p, s))
     assert err <= lat_tol and p >= mel_floor and s >= wav_floor
+
+
+def test_config5_precision_bf16_with_fp8_attention():
+    """BASELINE config 5's precision ("bf16 + fp8 MFMA attention") on the full-size config-1 run: bf16 engine
+    with the self-attention P.V products on the fp8 MFMA, against the fp32 oracle -- the same ladder as the bf16 row, so the
+    two lines in the log read as what the fp8 switch costs (floors leave ~6 dB of margin below the measured values)."""
+    r = config1_reference()
+    lat, mel, wav, _ = run_config1("bf16", attn_fp8=True)
+    err = (lat - r["lat"]).abs().max().item()
+    p, s = psnr(mel, r["mel"]), snr_db(wav, r["wav"])
+    print("config 1 bf16 + fp8 P.V attention vs fp32 oracle: latents max abs err %.3e, mel PSNR %.1f dB, waveform SNR %.1f dB" % (err, p, s))
+    assert err <= 4e-1 and p >= 36.0 and s >= 14.0
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
