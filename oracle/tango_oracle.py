@@ -197,7 +197,8 @@ class DDIMOracle:
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02,
                  beta_schedule="linear", clip_sample=True, set_alpha_to_one=True, steps_offset=0,
-                 prediction_type="epsilon", clip_sample_range=1.0, **_ignored):
+                 prediction_type="epsilon", clip_sample_range=1.0, eta=0.0, **_ignored):
+        self.eta = eta          # default for step(): the pipeline-level argument of the reference (models.py never passes one)
         if beta_schedule == "linear":
             self.betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
         elif beta_schedule == "scaled_linear":
@@ -234,8 +235,9 @@ class DDIMOracle:
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
         return ((1 - a_prev) / (1 - a_t)) * (1 - a_t / a_prev)
 
-    def step(self, model_output, t, sample, eta=0.0, noise=None, generator=None):  # :238-360
+    def step(self, model_output, t, sample, eta=None, noise=None, generator=None):  # :238-360
         t = int(t)
+        eta = self.eta if eta is None else eta
         prev_t = t - self.num_train_timesteps // self.num_inference_steps
         a_t = self.alphas_cumprod[t]
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod

@@ -276,11 +276,14 @@ static int launch_cfg(const GemmParams& p, hipStream_t s) {
 static bool small_tile_linear(const GemmParams& p, int esz) {
   if (tuning().no_small_tile || p.mode != GATHER_1D || p.epi != EPI_NONE || p.batch != 1 || p.splitk > 1 || p.bias_rows) return false;
   if (!(p.taps == 1 && p.rows_pb == p.M && p.in_mul == 1 && p.in_off == 0 && p.out_mul == 1 && p.out_off == 0 && p.Lin >= p.M)) return false;
-  if (p.N % 64 != 0 || (p.Cin * esz) % 128 != 0 || p.K > 2560) return false;
+  if (p.N % 64 != 0 || (p.Cin * esz) % 128 != 0 || p.K > 1280) return false;
   const int bn = (p.N % 160 == 0) ? 160 : 128;
   const long big = (long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
   const long small = (long)((p.M + 63) / 64) * (p.N / 64);
-  return big < 192 && small >= 96;
+  // measured at B = 1 (profiles/r3_c2_small_batch_dispatch_ab.txt; x25 / x20 / x5 per step, ms): M=2048 N=640 K=640 0.549 -> 0.430,
+  // M=8192 N=320 K=320 0.514 (streaming kernel) -> 0.301, M=8192 N=320 K=1280 0.173 -> 0.146; but M=512 N=1280 K=1280 0.540 -> 0.640
+  // and M=2048 N=640 K=2560 0.156 -> 0.212: a long serial k-loop on few workgroups loses to split-K
+  return big < 192 && (p.K <= 640 ? small >= 96 : small >= 512);
 }
 
 template <typename T, int BKB, int MODE>

@@ -386,7 +386,9 @@ bool linear_stream_ok(int dtype, const GemmParams& p) {
   if (p.epi != EPI_NONE && p.epi != EPI_GEGLU && p.epi != EPI_VT) return false;
   if (p.glu_tanh) return false;                     // the streaming epilogue implements the exact-erf gate only
   if (p.M < 4096) return false;                     // too few row groups to feed 256 CUs
-  if (tuning().stream_min_m_big && !p.ln_fold && p.M < 32768) return false;   // round-3 A/B: mid-size plain linears on the tile GEMMs
+  // plain linears below 16384 rows (B = 1's level 0) run faster as one launch of 64 x 64 tiles (gemm.hip small_tile_linear:
+  // x20 per step 0.514 -> 0.301 ms); at M = 16384 (B = 8's level 1) this kernel still wins (0.845 vs 1.014 ms on 128 x 160 tiles)
+  if (!p.ln_fold && p.epi == EPI_NONE && p.M < 16384 && !tuning().no_small_tile) return false;
   int tn;
   if (rowb == 640) tn = 10;
   else if (rowb == 1280) tn = 5;

@@ -19,8 +19,7 @@ struct Tuning {
   bool no_halo_conv;        // TANGO_NO_HALO_CONV=1     A/B: conv3x3_halo_kernel (256 x 160 halo conv) out
   bool no_dma_gemm;         // TANGO_NO_DMA_GEMM=1      A/B: gemm_dma_kernel (256 x 160 gather GEMM) out
   bool no_stream;           // TANGO_NO_STREAM=1        A/B: lin_stream_kernel out (plain linears only; folded-LN shapes need it)
-  bool no_small_tile;       // TANGO_NO_SMALL_TILE=1    A/B: 64 x 64 tiles for small-M linears out (back to split-K + reduce) (round 3)
-  bool stream_min_m_big;    // TANGO_STREAM_BIG_M=1     A/B: streaming linear only from M >= 32768 (plain linears below go to tile GEMMs) (round 3)
+  bool no_small_tile;       // TANGO_NO_SMALL_TILE=1    A/B: 64 x 64 tiles for small-M linears out (back to split-K + reduce / the streaming kernel) (round 3)
   bool no_xattn_fused;      // TANGO_NO_XATTN_FUSED=1   A/B: fused cross-attention block kernel out (round 3)
   bool no_gn_fused_stats;   // TANGO_NO_GN_EPI_STATS=1  A/B: GroupNorm statistics from the producer's epilogue out (round 3)
 };
@@ -36,7 +35,6 @@ inline const Tuning& tuning() {
     x.no_dma_gemm = on("TANGO_NO_DMA_GEMM");
     x.no_stream = on("TANGO_NO_STREAM");
     x.no_small_tile = on("TANGO_NO_SMALL_TILE");
-    x.stream_min_m_big = on("TANGO_STREAM_BIG_M");
     x.no_xattn_fused = on("TANGO_NO_XATTN_FUSED");
     x.no_gn_fused_stats = on("TANGO_NO_GN_EPI_STATS");
     return x;

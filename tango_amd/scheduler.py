@@ -116,12 +116,20 @@ class DDPMScheduler(_SchedulerBase):
 
 
 class DDIMScheduler(_SchedulerBase):
-    """Deterministic (eta = 0) DDIM rule: scheduling_ddim.py; the north-star's optional sampler."""
+    """DDIM rule (fork schedulers/scheduling_ddim.py:238-360; AudioLDM's DDIMSampler.p_sample_ddim, audioldm/latent_diffusion/
+    ddim.py:306-377, is the same update): the north-star's optional sampler.  `eta` = 0 (default) is the deterministic rule;
+    eta > 0 adds sigma_t = eta * sqrt((1 - abar_prev) / (1 - abar_t) * (1 - abar_t / abar_prev)) of fresh noise per step and
+    shortens the direction term to sqrt(1 - abar_prev - sigma_t^2) (scheduling_ddim.py:316-352, ddim.py:356-370; eta = 1 is
+    DDPM-like ancestral sampling).  The noise comes from the engine's step-noise source (injected tensor or device Philox),
+    like the DDPM rule's."""
     rule = "ddim"
 
-    def __init__(self, set_alpha_to_one=True, steps_offset=0, **kw):
+    def __init__(self, set_alpha_to_one=True, steps_offset=0, eta=0.0, **kw):
         super().__init__(set_alpha_to_one=set_alpha_to_one, steps_offset=steps_offset, **kw)
         self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        if eta < 0:
+            raise ValueError("eta must be >= 0")
+        self.eta = float(eta)
 
     def set_timesteps(self, num_inference_steps, device=None):
         self.timesteps = torch.from_numpy(self._base_timesteps(num_inference_steps)) + self.config.steps_offset
@@ -134,6 +142,8 @@ class DDIMScheduler(_SchedulerBase):
             a_t = self.alphas_cumprod[t]
             a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
             b_t = 1 - a_t
-            direction = (1 - a_prev) ** 0.5            # eta = 0 -> std_dev_t = 0
-            rows.append([float(a_t ** 0.5), float(b_t ** 0.5), 0.0, 0.0, 0.0, float(a_prev ** 0.5), float(direction), 0.0])
+            var = ((1 - a_prev) / (1 - a_t)) * (1 - a_t / a_prev)          # scheduling_ddim.py:184-193
+            std = self.eta * var ** 0.5                                      # :316-317 (eta = 0 -> std_dev_t = 0)
+            direction = (1 - a_prev - std ** 2) ** 0.5                       # :340
+            rows.append([float(a_t ** 0.5), float(b_t ** 0.5), 0.0, 0.0, float(std), float(a_prev ** 0.5), float(direction), 0.0])
         return np.asarray(rows, dtype=np.float32)

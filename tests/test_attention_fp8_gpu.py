@@ -52,11 +52,17 @@ def test_attention_fp8_pv(lib, dtype, B, heads, S, spread):
     C_ = heads * 64
     q = q16(torch.randn(B, S, C_, generator=g) * spread, dtype)
     k = q16(torch.randn(B, S, C_, generator=g), dtype)
-    v = q16(torch.randn(B, S, C_, generator=g) * 1.5 + 0.3, dtype)
-    v[0, 0, 0] = 1000.0                      # beyond the e4m3 range: clamped, not inf / NaN
+    # V on the e4m3 grid (exactly representable in fp16 and bf16), so the comparison with the emulation does not hinge on how a
+    # TIE is rounded when the kernel converts V: bf16 values fall exactly half-way between two e4m3 neighbours 1 time in 16
+    # (measured: a bf16 flat-attention case differed from torch's round-half-even emulation by 1.7e-2 while being 1.2e-2 from
+    # the exact result); general V is covered by the exact-softmax bound below through `v_any`
+    v = f8(torch.randn(B, S, C_, generator=g) * 1.5 + 0.3)
+    v[0, 0, 0] = 1000.0                      # beyond the e4m3 range: clamped to 448 by the kernel, not inf / NaN
     v = q16(v, dtype)
     qh, kh, vh = (t.view(B, S, heads, 64).transpose(1, 2) for t in (q, k, v))
-    exact = ((qh @ kh.transpose(-1, -2) * 0.125).softmax(-1) @ vh.clamp(-448, 448)).transpose(1, 2).reshape(B, S, C_)
+    attn = (qh @ kh.transpose(-1, -2) * 0.125).softmax(-1)
+    exact = (attn @ vh.clamp(-448, 448)).transpose(1, 2).reshape(B, S, C_)
+    exact_unclamped = (attn @ vh).transpose(1, 2).reshape(B, S, C_)
     emu = emulate(qh, kh, vh, 0.125).transpose(1, 2).reshape(B, S, C_)
     out = torch.empty(B, S, C_, device="cuda")
     p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
@@ -77,7 +83,17 @@ def test_attention_fp8_pv(lib, dtype, B, heads, S, spread):
     # and the switch is really on: the 16-bit kernel on the same inputs is closer to the exact result
     base = torch.empty(B, S, C_, device="cuda")
     assert lib.tango_op_attention_ex(DT[dtype], p(qd), p(kd), p(vd), None, p(base), B, heads, S, S, 0.125, 0, None) == 0
-    assert (base.cpu() - exact).abs().max().item() / scale < e_exact
+    assert (base.cpu() - exact_unclamped).abs().max().item() / exact_unclamped.abs().max().item() < e_exact
+    # general (off-grid) V: only the loose bound applies
+    v_any = q16(torch.randn(B, S, C_, generator=g) * 1.5 + 0.3, dtype)
+    va = v_any.view(B, S, heads, 64).transpose(1, 2)
+    ex2 = (attn @ va).transpose(1, 2).reshape(B, S, C_)
+    vd2 = v_any.cuda()
+    assert lib.tango_op_attention_ex(DT[dtype], p(qd), p(kd), p(vd2), None, p(out_dev := torch.empty(B, S, C_, device="cuda")), B, heads, S, S,
+                                     0.125, 1, None) == 0
+    e2 = (out_dev.cpu() - ex2).abs().max().item() / ex2.abs().max().item()
+    print("   off-grid V: vs exact %.3e" % e2)
+    assert e2 <= 8e-2
 
 
 def test_fp8_pv_argument_errors(lib):

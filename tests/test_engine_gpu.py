@@ -178,6 +178,35 @@ def test_denoise_loop_tiny(dtype, sched_name):
     assert tot > 0 and per > 0
 
 
+@pytest.mark.parametrize("eta", [0.5, 1.0])
+def test_denoise_loop_ddim_eta(eta):
+    """DDIM with eta > 0 (scheduling_ddim.py:316-352; audioldm/latent_diffusion/ddim.py:356-370): the stochastic term uses the
+    step-noise source like the DDPM rule's; injected noise, fp32 engine vs the oracle's DDIM step"""
+    cfg = O.UNET_CONFIG_TINY
+    e = unet_engine("tiny", "fp32")
+    B, L, N = 2, 9, 4
+    enc, mask = text_inputs(2 * B, L, cfg["cross_attention_dim"], 41)
+    g = torch.Generator().manual_seed(42)
+    lat0 = torch.randn(B, 8, 256, 16, generator=g)
+    noises = torch.randn(N, B, 8, 256, 16, generator=g)
+    osch = O.DDIMOracle(**dict(O.SD21_SCHEDULER, set_alpha_to_one=False, steps_offset=1, eta=eta))
+    keys = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "prediction_type", "clip_sample", "set_alpha_to_one", "steps_offset")
+    sch = DDIMScheduler.from_config(dict({k: SD21_SCHEDULER_CONFIG[k] for k in keys}, eta=eta))
+    ref = O.denoise_loop(unet_sd("tiny"), cfg, osch, enc, mask, lat0.clone(), N, 3.0, noises=list(noises), prefix="unet.")
+    sch.set_timesteps(N)
+    assert sch.timesteps.tolist() == osch.timesteps.tolist() and sch.coef_table()[:, 4].min() > 0
+    lat = lat0.clone().cuda()
+    e.denoise(lat, enc.cuda(), mask.cuda(), sch.timesteps.numpy(), sch.coef_table(), 3.0, prediction_type="v_prediction", rule="ddim",
+              noise=noises.cuda())
+    err = (lat.cpu() - ref).abs().max().item()
+    det = lat0.clone().cuda()
+    d0 = DDIMScheduler.from_config({k: SD21_SCHEDULER_CONFIG[k] for k in keys})
+    d0.set_timesteps(N)
+    e.denoise(det, enc.cuda(), mask.cuda(), d0.timesteps.numpy(), d0.coef_table(), 3.0, prediction_type="v_prediction", rule="ddim")
+    print("DDIM eta=%.1f fp32: max abs err vs oracle %.3e; distance from the eta = 0 trajectory %.2f" % (eta, err, (lat - det).abs().max().item()))
+    assert err <= 1e-2 and (lat - det).abs().max().item() > 0.1
+
+
 @pytest.mark.parametrize("guidance,pred,B", [(1.0, "v_prediction", 3), (0.0, "v_prediction", 1), (3.0, "epsilon", 3), (7.5, "sample", 1)])
 def test_denoise_loop_edge_cases(guidance, pred, B):
     """models.py:224-249 off the beaten path: guidance <= 1 runs WITHOUT the unconditional twin (UNet batch B, not 2B;

@@ -117,6 +117,24 @@ def test_scheduler_surface_and_errors():
                       prediction_type="v_prediction", clip_sample=False, set_alpha_to_one=False, steps_offset=1)
     d.set_timesteps(200)
     assert d.timesteps.tolist() == list(range(996, 0, -5)) and d.rule == "ddim"
+    t0 = d.coef_table()
+    assert (t0[:, 4] == 0).all()                                        # eta = 0: no noise term
+    # eta > 0 (scheduling_ddim.py:316-352): sigma = eta * sqrt(var), direction^2 + sigma^2 = 1 - abar_prev
+    from oracle import tango_oracle as O
+    d1 = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                       prediction_type="v_prediction", clip_sample=False, set_alpha_to_one=False, steps_offset=1, eta=0.7)
+    d1.set_timesteps(200)
+    t1 = d1.coef_table()
+    o = O.DDIMOracle(**dict(O.SD21_SCHEDULER, set_alpha_to_one=False, steps_offset=1))
+    o.set_timesteps(200)
+    for i in (0, 57, 199):
+        t = int(o.timesteps[i]); pt = t - 5
+        var = float(o._variance(t, pt))
+        assert abs(t1[i, 4] - 0.7 * var ** 0.5) < 1e-6
+        a_prev = float(o.alphas_cumprod[pt] if pt >= 0 else o.final_alpha_cumprod)
+        assert abs(t1[i, 6] ** 2 + t1[i, 4] ** 2 - (1 - a_prev)) < 1e-6 and t1[i, 5] == t0[i, 5]
+    with pytest.raises(ValueError):
+        DDIMScheduler(eta=-1.0)
 
 
 def test_batch_inference_driver_writes_reference_layout(tmp_path):

@@ -26,8 +26,10 @@ def test_music_unet_forward_tiny(dtype, tol):
     cfg = O.UNET_CONFIG_MUSIC_TINY
     e = Engine(unet=cfg, dtype=dtype)
     assert len(e.weight_names()) == len(W.unet_param_shapes(cfg, "unet."))
-    e.load_synthetic(1234)
+    # the same tensors as the reference fixture was made with: oracle/make_golden.py draws them under the UNPREFIXED key names
     sd = W.synth_state_dict(W.unet_param_shapes(cfg), 1234)
+    e.load_state_dict({"unet." + k: v for k, v in sd.items()})
+    e.finalize()
     x, enc, beat, chord, em, bm, cm = music_inputs(cfg, 4, 3)
     out = e.unet_forward(x.cuda(), 801, enc.cuda(), em.cuda(), beat.cuda(), chord.cuda(), bm.cuda(), cm.cuda()).cpu()
     with torch.no_grad():
@@ -60,8 +62,8 @@ def test_music_denoise_loop_tiny(dtype, tol):
     """mustango/models.py:563-598: CFG loop, three conditions ordered [uncond; cond], injected noise, hipGraph == eager bitwise"""
     cfg = O.UNET_CONFIG_MUSIC_TINY
     m = MusicAudioDiffusion(unet_config=cfg, dtype=dtype)
-    m.engine.load_synthetic(1234)
     sd = W.synth_state_dict(W.unet_param_shapes(cfg), 1234)
+    m.load_state_dict({"unet." + k: v for k, v in sd.items()})
     B, N = 2, 3
     _, enc, beat, chord, em, bm, cm = music_inputs(cfg, 2 * B, 11)
     g = torch.Generator().manual_seed(12)
@@ -92,9 +94,11 @@ def test_music_unet_forward_full_size(dtype, tol):
     chord_len 20 (mustango/models.py:336,340), one CFG pair"""
     cfg = O.UNET_CONFIG_MUSIC
     e = Engine(unet=cfg, dtype=dtype)
-    e.load_synthetic(1234)
     sd = W.synth_state_dict(W.unet_param_shapes(cfg), 1234)
     assert len(sd) == 1518
+    for k in e.weight_names():                         # tensor by tensor: 1.4 G parameters
+        e.set_weight(k, sd[k[len("unet."):]])
+    e.finalize()
     x, enc, beat, chord, em, bm, cm = music_inputs(cfg, 2, 5, L=64)
     out = e.unet_forward(x.cuda(), 500, enc.cuda(), em.cuda(), beat.cuda(), chord.cuda(), bm.cuda(), cm.cuda()).cpu()
     with torch.no_grad():
