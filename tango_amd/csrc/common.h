@@ -182,6 +182,8 @@ struct GemmParams {
 };
 
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s);
+enum GemmRoute : int { ROUTE_NONE = 0, ROUTE_WIDE, ROUTE_STREAM, ROUTE_CONV_WIDE, ROUTE_CONV_HALO, ROUTE_DMA, ROUTE_TILE };
+int gemm_route(int dtype, const GemmParams& p);   // which kernel family launch_gemm() picks for this problem
 bool conv_halo_ok(int dtype, const GemmParams& p);
 int launch_conv_halo(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s);
 bool gemm_wide_ok(int dtype, const GemmParams& p);   // 256 x 320 ping-pong LDS-DMA GEMM for the big 16-bit linears (gemm_wide.hip)

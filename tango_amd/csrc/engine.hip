@@ -102,7 +102,7 @@ struct Builder {
       GemmParams q = p;
       q.W = w.Wln; q.bias = w.bln; q.ln_fold = 1; q.ln_eps = o.ln->eps; q.wsum = w.wsum;
       if (w.Wln && (linear_stream_ok(dt, q) || gemm_wide_ok(dt, q))) {
-        gemm(q, gemm_wide_ok(dt, q) ? "linear+ln(wide)" : "linear+ln(stream)");
+        gemm(q, gemm_route(dt, q) == ROUTE_WIDE ? "linear+ln(wide)" : "linear+ln(stream)");
         return;
       }
       // fallback: materialise LayerNorm(x), then the plain GEMM
@@ -114,7 +114,8 @@ struct Builder {
       A.release(m);
       return;
     }
-    gemm(p, linear_stream_ok(dt, p) ? "linear(stream)" : "linear");
+    const int route = gemm_pick_splitk(dt, p) > 1 ? ROUTE_TILE : gemm_route(dt, p);
+    gemm(p, route == ROUTE_STREAM ? "linear(stream)" : route == ROUTE_WIDE ? "linear(wide)" : "linear");
   }
 
   // 3x3 conv (pad 1) on NHWC: output grid B x H x W; source B x Hin x Win (nearest-upsampled x2 when ups)

@@ -360,18 +360,36 @@ int gemm_pick_splitk(int dtype, const GemmParams& p) {
   return s < 2 ? 1 : s;
 }
 
+// Which kernel family takes this problem (one decision, used by the launcher AND by the per-op profile labels).
+int gemm_route(int dtype, const GemmParams& p) {
+  if (!p.ln_fold && gemm_wide_ok(dtype, p)) {
+    // the 256 x 320 kernel beats the streaming kernel on plain (no folded LayerNorm) shapes once a row is >= 1280 bytes (round 2:
+    // M=65536 N=640 K=640 x20 2.38 -> 1.87 ms), takes the transposed-V and short-row (conv_in im2col, K = 96) shapes the streaming
+    // kernel has no instantiation for, and -- round 3, profiles/r3_c3_level0_plain_linear_kernel_ab.txt -- also wins the level-0
+    // K = 320 rows at config-3 size (M=262144 N=320 K=320 x20: 2.81 -> 2.33 ms) as long as the grid is a few tiles per CU
+    const long tiles = (long)(p.M / 256) * (p.N / 320);
+    if (p.K >= 640 || p.epi == EPI_VT || !linear_stream_ok(dtype, p) || tiles >= tuning().exp_wide320_min_tiles) return ROUTE_WIDE;
+  }
+  if (p.ln_fold && gemm_wide_ok(dtype, p)) return ROUTE_WIDE;
+  if (linear_stream_ok(dtype, p)) return ROUTE_STREAM;
+  if (p.ln_fold) return ROUTE_NONE;
+  if (conv_wide_ok(dtype, p)) return ROUTE_CONV_WIDE;
+  if (conv_halo_ok(dtype, p)) return ROUTE_CONV_HALO;
+  if (gemm_wide_ok(dtype, p)) return ROUTE_WIDE;
+  if (gemm_dma_ok(dtype, p)) return ROUTE_DMA;
+  return ROUTE_TILE;
+}
+
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
-  // the 256 x 320 kernel also beats the streaming kernel on its plain (no folded LayerNorm) shapes once a row is >= 1280 bytes
-  // (measured, same box: M=65536 N=640 K=640 x20 2.38 -> 1.87 ms; K=320 rows: no difference, stay on the streaming kernel)
-  // ... and short rows the streaming kernel has no instantiation for (conv_in as im2col + linear, K = 96: 207 -> ~50 us)
-  if (!p.ln_fold && (p.K >= 640 || p.epi == EPI_VT || !linear_stream_ok(dtype, p)) && gemm_wide_ok(dtype, p)) return launch_gemm_wide(dtype, p, s);
-  if (p.ln_fold && gemm_wide_ok(dtype, p)) return launch_gemm_wide(dtype, p, s);
-  if (linear_stream_ok(dtype, p)) return launch_linear_stream(dtype, p, s);
-  if (p.ln_fold) TANGO_FAIL("gemm: ln_fold is only implemented by the streaming linear kernel");
-  if (conv_wide_ok(dtype, p)) return launch_conv_wide(dtype, p, g_zero_page, s);
-  if (conv_halo_ok(dtype, p)) return launch_conv_halo(dtype, p, g_zero_page, s);
-  if (gemm_wide_ok(dtype, p)) return launch_gemm_wide(dtype, p, s);
-  if (gemm_dma_ok(dtype, p)) return launch_gemm_dma(dtype, p, g_zero_page, s);
+  switch (gemm_route(dtype, p)) {
+    case ROUTE_WIDE: return launch_gemm_wide(dtype, p, s);
+    case ROUTE_STREAM: return launch_linear_stream(dtype, p, s);
+    case ROUTE_CONV_WIDE: return launch_conv_wide(dtype, p, g_zero_page, s);
+    case ROUTE_CONV_HALO: return launch_conv_halo(dtype, p, g_zero_page, s);
+    case ROUTE_DMA: return launch_gemm_dma(dtype, p, g_zero_page, s);
+    case ROUTE_NONE: TANGO_FAIL("gemm: ln_fold is only implemented by the streaming linear and the 256 x 320 GEMM kernels");
+    default: break;
+  }
   switch (dtype) {
     case DT_F32: return launch_t<float>(p, s);
     case DT_F16: return launch_t<f16>(p, s);

@@ -220,7 +220,10 @@ bool gemm_wide_ok(int dtype, const GemmParams& p) {
   // folded LayerNorm: measured against the alternatives on one box -- K = 320 rows stay on the streaming kernel, and for the
   // GEGLU shapes (N = 8 C) the separate LayerNorm kernel + plain wide GEMM is as fast or faster (row statistics cost 32 VALU
   // instructions per k-chunk inside the MFMA phase); the narrow projections (N <= 3 C) gain 25-30 %
-  if (p.ln_fold && (p.epi == EPI_GEGLU || p.K < 640)) return false;
+  if (p.ln_fold) {
+    const int ex = tuning().exp_wide_ln320;      // round-3 experiment bits: 1 = K < 640 narrow projections, 2 = GEGLU with K < 640
+    if (p.epi == EPI_GEGLU ? !(p.K < 640 && (ex & 2)) : (p.K < 640 && !(ex & 1))) return false;
+  }
   if (p.e_act != ACT_NONE) return false;            // (an inlined activation switch per element bloated this kernel 10x: not supported here)
   if (p.M % 256 != 0 || p.N % 320 != 0 || (p.K * 2) % 64 != 0) return false;
   if (p.ldo % 8 != 0 || ((uintptr_t)p.out & 15) || (p.R && (p.ldr % 8 != 0 || ((uintptr_t)p.R & 15)))) return false;
