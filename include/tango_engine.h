@@ -225,6 +225,11 @@ int tango_op_attention(int dtype, const float* q, const float* k, const float* v
 /* as tango_op_attention; flags bit 0: P.V on the fp8 MFMA (16-bit dtypes, no bias, Skv % 64 == 0) */
 int tango_op_attention_ex(int dtype, const float* q, const float* k, const float* v, const float* bias, float* out, int B, int heads,
                           int Sq, int Skv, float scale, int flags, void* stream);
+/* fused cross-attention block of BasicTransformerBlock (diffusers attention.py:312-323: attn2(norm2(x), text, mask) + x) as the engine
+   runs it at level 0 (C = 320, 5 heads, 64 text tokens): x [B*HW, 320]; wq / wo [320, 320] Linear weights (to_q has no bias);
+   k, v [B*L, 320] = to_k / to_v of the text; bias [B, L] additive or NULL */
+int tango_op_xattn_block(int dtype, const float* x, const float* gamma, const float* beta, const float* wq, const float* k, const float* v,
+                         const float* bias, const float* wo, const float* bo, float* out, int B, int HW, int L, float eps, void* stream);
 int tango_op_sched_step(float* latents, const float* model_out_nchw, const float* noise, const float* coef8, int B, int C, int HW,
                         int cfg, float guidance, int pred_type, int rule, int clip, float clip_range, void* stream);
 

@@ -104,7 +104,7 @@ SYMBOLS = [
     "tango_engine_vae_decode", "tango_engine_vae_encode", "tango_engine_vocode", "tango_engine_vocoder_samples", "tango_engine_encode_text",
     "tango_engine_mel_frames", "tango_engine_mel_spectrogram",
     "tango_engine_last_denoise_ms", "tango_engine_profile_unet", "tango_op_conv2d", "tango_op_linear", "tango_op_linear_ln", "tango_op_linear_qkv", "tango_op_conv1d",
-    "tango_op_conv_transpose1d", "tango_op_groupnorm", "tango_op_layernorm", "tango_op_attention", "tango_op_attention_ex",
+    "tango_op_conv_transpose1d", "tango_op_groupnorm", "tango_op_layernorm", "tango_op_attention", "tango_op_attention_ex", "tango_op_xattn_block",
     "tango_op_sched_step", "tango_op_philox_normal",
 ]
 
@@ -154,6 +154,7 @@ def load():
     lib.tango_op_layernorm.argtypes = [ci, vp, vp, vp, vp, ci, ci, cf, vp]
     lib.tango_op_attention.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp]
     lib.tango_op_attention_ex.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, ci, vp]
+    lib.tango_op_xattn_block.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, vp]
     lib.tango_op_sched_step.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, cf, ci, ci, ci, cf, vp]
     lib.tango_op_philox_normal.argtypes = [vp, ci, ci, ci, ci, C.c_uint64, ci, vp]
     _lib = lib

@@ -234,6 +234,24 @@ struct AttnParams {
 };
 int launch_attention(int dtype, const AttnParams& p, hipStream_t s);
 
+// ---- fused cross-attention block (xattn.hip): y = x + to_out(softmax(to_q(LayerNorm(x)) K^T / 8 + bias) V) + b_out ----
+struct XAttnParams {
+  const void* x; int64_t ldx;          // [M][C] T: the residual stream (LayerNorm input AND residual)
+  const void* wq;                      // [C][C] T: LayerNorm-folded to_q weight, rows permuted per head (launch_xattn_permute_wq)
+  const float* bq; const float* wsum;  // [C] fp32, permuted like wq's rows: folded bias b' = W beta, wsum = sum_k W'[n][k]
+  const void* k; int64_t ldk;          // [B*L][C] T: to_k(text)   (step-invariant, computed once per call)
+  const void* vt; int64_t ldvt;        // [B][C][ldvt] T: to_v(text) transposed
+  const float* bias;                   // [B][L] fp32 additive mask bias or null
+  const void* wo; int64_t ldwo;        // [C][C] T: to_out.0 weight, natural layout
+  const float* bo;                     // [C] fp32
+  void* out; int64_t ldo;              // [M][C] T
+  int M, HW, L;                        // rows, rows per sample, text tokens
+  float eps, scale;
+};
+bool xattn_block_ok(int dtype, int C, int heads, int HW, int L, int64_t ldx, int64_t ldo, int64_t ldk, int64_t ldvt);
+int launch_xattn_block(int dtype, const XAttnParams& p, hipStream_t s);
+int launch_xattn_permute_wq(int dtype, const void* W, const float* b, const float* wsum, void* Wp, float* bp, float* wsp, int C, hipStream_t s);
+
 // row softmax (in place) used by the VAE single-head 512-d attention: x[rows][cols] *= scale; softmax
 int launch_softmax_rows(int dtype, void* x, int64_t ld, int rows, int cols, float scale, hipStream_t s);
 

@@ -85,6 +85,10 @@ struct XfW {             // Transformer2DModel with one BasicTransformerBlock
   int cond = 0;          // which condition its cross-attention reads: 0 text, 1 beat, 2 chord (Music UNet: attentions / attentions2 / attentions3)
   WNorm gn, ln1, ln2, ln3;
   WMat proj_in, qkv, o1, q2, kv2, o2, ff1, ff2, proj_out;
+  // fused cross-attention block (xattn.hip; C = 320 on 16-bit engines): LayerNorm-folded to_q with rows permuted per head
+  void* q2p = nullptr;
+  float* bq2p = nullptr;
+  float* wsum2p = nullptr;
 };
 struct VaeAttnW {
   WNorm gn;

@@ -265,11 +265,25 @@ struct Builder {
               E.cfg.unet_attn_fp8 != 0 && dt != DT_F32 && HW % 64 == 0);
     TView h1 = alloc(rows, C);
     { GOpt o; o.residual = &h; linear(a, rows, w.o1, h1, o); }
-    TView q = slice(qkv, 0, C, esz);   // reuse the qkv buffer for the cross-attention query
-    { GOpt o = nb; o.ln = &w.ln2; linear(h1, rows, w.q2, q, o); }
-    attention(q, kv, kvt, (L + 7) / 8 * 8, a, bias, B, w.heads, HW, L);
     TView h2 = h;                       // h is dead after h1 was produced
-    { GOpt o; o.residual = &h1; linear(a, rows, w.o2, h2, o); }
+    const int Lp8 = (L + 7) / 8 * 8;
+    if (w.q2p && xattn_block_ok(dt, C, w.heads, HW, L, h1.ld, h2.ld, kv.ld, Lp8)) {
+      // norm2 -> attn2 (to_q, softmax(Q K^T) V over the 64 text tokens, to_out) -> + residual in ONE launch (xattn.hip)
+      XAttnParams xp;
+      xp.x = h1.p; xp.ldx = h1.ld; xp.wq = w.q2p; xp.bq = w.bq2p; xp.wsum = w.wsum2p;
+      xp.k = kv.p; xp.ldk = kv.ld; xp.vt = kvt; xp.ldvt = Lp8; xp.bias = bias;
+      xp.wo = w.o2.W; xp.ldwo = w.o2.Kp; xp.bo = w.o2.b; xp.out = h2.p; xp.ldo = h2.ld;
+      xp.M = (int)rows; xp.HW = HW; xp.L = L; xp.eps = w.ln2.eps; xp.scale = 0.125f;
+      const int d = dt;
+      push([xp, d](hipStream_t s) { return launch_xattn_block(d, xp, s); },
+           "xattn_block M=" + std::to_string(rows) + " C=" + std::to_string(C) + " L=" + std::to_string(L),
+           4.0 * rows * (double)C * C + 4.0 * rows * (double)L * C);
+    } else {
+      TView q = slice(qkv, 0, C, esz);   // reuse the qkv buffer for the cross-attention query
+      { GOpt o = nb; o.ln = &w.ln2; linear(h1, rows, w.q2, q, o); }
+      attention(q, kv, kvt, Lp8, a, bias, B, w.heads, HW, L);
+      { GOpt o; o.residual = &h1; linear(a, rows, w.o2, h2, o); }
+    }
     TView gg = alloc(rows, 4 * C);
     { GOpt o; o.epi = EPI_GEGLU; o.ln = &w.ln3; linear(h2, rows, w.ff1, gg, o); }
     TView h3 = h1;                      // h1 is dead after h2 was produced
@@ -771,6 +785,15 @@ int Engine::finalize_weights() {
     TANGO_TRY(fold_ln(x->qkv, x->ln1));
     TANGO_TRY(fold_ln(x->q2, x->ln2));
     TANGO_TRY(fold_ln(x->ff1, x->ln3));
+    if (dt != DT_F32 && x->C == 320 && x->heads == 5) {     // operands of the fused cross-attention block (xattn.hip)
+      if (!x->q2p) {
+        x->q2p = dmalloc((size_t)x->C * x->C * esz);
+        x->bq2p = (float*)dmalloc((size_t)x->C * 4);
+        x->wsum2p = (float*)dmalloc((size_t)x->C * 4);
+        if (!x->q2p || !x->bq2p || !x->wsum2p) return -1;
+      }
+      TANGO_TRY(launch_xattn_permute_wq(dt, x->q2.Wln, x->q2.bln, x->q2.wsum, x->q2p, x->bq2p, x->wsum2p, x->C, 0));
+    }
   }
   TANGO_HIP(hipDeviceSynchronize());
   temb_ts.clear();

@@ -366,9 +366,9 @@ int gemm_route(int dtype, const GemmParams& p) {
     // the 256 x 320 kernel beats the streaming kernel on plain (no folded LayerNorm) shapes once a row is >= 1280 bytes (round 2:
     // M=65536 N=640 K=640 x20 2.38 -> 1.87 ms), takes the transposed-V and short-row (conv_in im2col, K = 96) shapes the streaming
     // kernel has no instantiation for, and -- round 3, profiles/r3_c3_level0_plain_linear_kernel_ab.txt -- also wins the level-0
-    // K = 320 rows at config-3 size (M=262144 N=320 K=320 x20: 2.81 -> 2.33 ms) as long as the grid is a few tiles per CU
-    const long tiles = (long)(p.M / 256) * (p.N / 320);
-    if (p.K >= 640 || p.epi == EPI_VT || !linear_stream_ok(dtype, p) || tiles >= tuning().exp_wide320_min_tiles) return ROUTE_WIDE;
+    // K = 320 rows: M=262144 N=320 K=320 x20 2.81 -> 2.33 ms, and at B = 8 (M=65536, 256 tiles) 0.94 -> 0.74 ms
+    // (profiles/r3_c4_level0_ln_routing_ab.txt).  gemm_wide_ok() already demands >= 224 tiles.
+    return ROUTE_WIDE;
   }
   if (p.ln_fold && gemm_wide_ok(dtype, p)) return ROUTE_WIDE;
   if (linear_stream_ok(dtype, p)) return ROUTE_STREAM;

@@ -220,10 +220,13 @@ bool gemm_wide_ok(int dtype, const GemmParams& p) {
   // folded LayerNorm: measured against the alternatives on one box -- K = 320 rows stay on the streaming kernel, and for the
   // GEGLU shapes (N = 8 C) the separate LayerNorm kernel + plain wide GEMM is as fast or faster (row statistics cost 32 VALU
   // instructions per k-chunk inside the MFMA phase); the narrow projections (N <= 3 C) gain 25-30 %
-  if (p.ln_fold) {
-    const int ex = tuning().exp_wide_ln320;      // round-3 experiment bits: 1 = K < 640 narrow projections, 2 = GEGLU with K < 640
-    if (p.epi == EPI_GEGLU ? !(p.K < 640 && (ex & 2)) : (p.K < 640 && !(ex & 1))) return false;
-  }
+  // folded LayerNorm on this tile, measured (round 2; round 3 profiles/r3_c4_level0_ln_routing_ab.txt, ms per step at B = 32):
+  //   GEGLU shapes (N = 8 C): never -- the separate LayerNorm kernel + plain wide GEMM is as fast at levels 1-2, and at level 0
+  //   (K = 320) the streaming kernel wins outright (x5: 3.27 vs 4.06);
+  //   narrow projections (N <= 3 C): levels 1-2 gain 25-30 %; level 0 (K = 320) q | k | v^T x5 1.63 -> 1.47 and attn2.to_q x5
+  //   0.59 -> 0.53 at M = 262144, but at M = 65536 (B = 8) the q | k | v^T shape is ~6 % slower here (0.405 vs 0.431): K < 640
+  //   comes here from 131072 rows on, or when the whole problem is one column of tiles
+  if (p.ln_fold && (p.epi == EPI_GEGLU || (p.K < 640 && p.M < 131072 && p.N > 320))) return false;
   if (p.e_act != ACT_NONE) return false;            // (an inlined activation switch per element bloated this kernel 10x: not supported here)
   if (p.M % 256 != 0 || p.N % 320 != 0 || (p.K * 2) % 64 != 0) return false;
   if (p.ldo % 8 != 0 || ((uintptr_t)p.out & 15) || (p.R && (p.ldr % 8 != 0 || ((uintptr_t)p.R & 15)))) return false;

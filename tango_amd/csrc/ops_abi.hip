@@ -364,6 +364,40 @@ int tango_op_attention_ex(int dt, const float* q, const float* k, const float* v
   return 0;
 }
 
+int tango_op_xattn_block(int dt, const float* x, const float* gamma, const float* beta, const float* wq, const float* k, const float* v,
+                         const float* bias, const float* wo, const float* bo, float* out, int B, int HW, int L, float eps, void* stream) {
+  // y = x + to_out(softmax(to_q(LayerNorm(x)) K^T / 8 + bias) V) + bo in the fused kernel (xattn.hip); C = 320, 5 heads.
+  // x [B*HW, 320]; wq, wo [320, 320] (Linear layout, to_q has no bias); k, v [B*L, 320] = to_k / to_v of the text; bias [B, L] or NULL
+  hipStream_t s = (hipStream_t)stream;
+  const int C = 320, heads = 5;
+  const size_t esz = dtype_size(dt);
+  const int64_t M = (int64_t)B * HW, ldvt = (L + 7) / 8 * 8;
+  if (!xattn_block_ok(dt, C, heads, HW, L, C, C, C, ldvt)) TANGO_FAIL("op_xattn_block: shape / dtype not supported by the fused kernel");
+  Scratch sc;
+  void* xt = sc.get(M * C * esz); void* ot = sc.get(M * C * esz);
+  void* wqt = sc.get((size_t)C * C * esz); void* wql = sc.get((size_t)C * C * esz); void* wqp = sc.get((size_t)C * C * esz);
+  void* wot = sc.get((size_t)C * C * esz);
+  void* kt = sc.get((size_t)B * L * C * esz); void* vt = sc.get((size_t)B * L * C * esz); void* vtt = sc.get((size_t)B * C * ldvt * esz);
+  float* bl = (float*)sc.get(C * 4); float* ws = (float*)sc.get(C * 4); float* bp = (float*)sc.get(C * 4); float* wsp = (float*)sc.get(C * 4);
+  if (!xt || !ot || !wqt || !wql || !wqp || !wot || !kt || !vt || !vtt || !bl || !ws || !bp || !wsp) TANGO_FAIL("op_xattn_block: alloc");
+  TANGO_HIP(hipMemsetAsync(vtt, 0, (size_t)B * C * ldvt * esz, s));
+  TANGO_TRY(launch_cast_rows(dt, x, xt, C, (int)M, C, s));
+  TANGO_TRY(launch_pack(dt, wq, wqt, C, 1, C, C, 0, 1, C, 0, s));
+  TANGO_TRY(launch_pack(dt, wo, wot, C, 1, C, C, 0, 1, C, 0, s));
+  TANGO_TRY(launch_cast_rows(dt, k, kt, C, B * L, C, s));
+  TANGO_TRY(launch_cast_rows(dt, v, vt, C, B * L, C, s));
+  TANGO_TRY(transpose_v(dt, vt, vtt, B, L, C, ldvt, s));
+  TANGO_TRY(launch_fold_ln(dt, wqt, C, gamma, beta, nullptr, wql, bl, ws, C, C, s));
+  TANGO_TRY(launch_xattn_permute_wq(dt, wql, bl, ws, wqp, bp, wsp, C, s));
+  XAttnParams p;
+  p.x = xt; p.ldx = C; p.wq = wqp; p.bq = bp; p.wsum = wsp; p.k = kt; p.ldk = C; p.vt = vtt; p.ldvt = ldvt; p.bias = bias;
+  p.wo = wot; p.ldwo = C; p.bo = bo; p.out = ot; p.ldo = C; p.M = (int)M; p.HW = HW; p.L = L; p.eps = eps; p.scale = 0.125f;
+  TANGO_TRY(launch_xattn_block(dt, p, s));
+  TANGO_TRY(to_f32(dt, ot, C, out, M, C, s));
+  TANGO_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 int tango_op_sched_step(float* latents, const float* model_out_nchw, const float* noise, const float* coef8, int B, int C, int HW,
                         int cfg, float guidance, int pred_type, int rule, int clip, float clip_range, void* stream) {
   hipStream_t s = (hipStream_t)stream;

@@ -20,8 +20,6 @@ struct Tuning {
   bool no_dma_gemm;         // TANGO_NO_DMA_GEMM=1      A/B: gemm_dma_kernel (256 x 160 gather GEMM) out
   bool no_stream;           // TANGO_NO_STREAM=1        A/B: lin_stream_kernel out (plain linears only; folded-LN shapes need it)
   bool no_small_tile;       // TANGO_NO_SMALL_TILE=1    A/B: 64 x 64 tiles for small-M linears out (back to split-K + reduce / the streaming kernel) (round 3)
-  int exp_wide320_min_tiles;   // TANGO_EXP_WIDE320_TILES=n  round-3 experiment: plain K < 640 linears go to the 256 x 320 GEMM from n tiles on
-  int exp_wide_ln320;          // TANGO_EXP_WIDE_LN320=bits  round-3 experiment: folded-LN K = 320 shapes on the 256 x 320 GEMM (1: N = 320 / q|k|v^T, 2: GEGLU)
   bool no_xattn_fused;      // TANGO_NO_XATTN_FUSED=1   A/B: fused cross-attention block kernel out (round 3)
   bool no_gn_fused_stats;   // TANGO_NO_GN_EPI_STATS=1  A/B: GroupNorm statistics from the producer's epilogue out (round 3)
 };
@@ -37,8 +35,6 @@ inline const Tuning& tuning() {
     x.no_dma_gemm = on("TANGO_NO_DMA_GEMM");
     x.no_stream = on("TANGO_NO_STREAM");
     x.no_small_tile = on("TANGO_NO_SMALL_TILE");
-    x.exp_wide320_min_tiles = getenv("TANGO_EXP_WIDE320_TILES") ? atoi(getenv("TANGO_EXP_WIDE320_TILES")) : 512;
-    x.exp_wide_ln320 = getenv("TANGO_EXP_WIDE_LN320") ? atoi(getenv("TANGO_EXP_WIDE_LN320")) : 0;
     x.no_xattn_fused = on("TANGO_NO_XATTN_FUSED");
     x.no_gn_fused_stats = on("TANGO_NO_GN_EPI_STATS");
     return x;

@@ -1,0 +1,338 @@
+// Fused cross-attention block of BasicTransformerBlock (round 3): for a 128-row tile of the residual stream,
+//
+//   y = x + to_out( softmax( to_q(LayerNorm2(x)) . K^T / sqrt(64) + mask_bias ) . V ) + b_out
+//
+// i.e. the reference's  `hidden_states = attn2(norm2(hidden_states), encoder_hidden_states, mask) + hidden_states`
+// (mustango/diffusers/src/diffusers/models/attention.py:312-323; Attention / AttnProcessor2_0, attention_processor.py:495-540)
+// in ONE kernel.  Why it fuses: with 64 text tokens every stage is row-local -- a query row needs only its own LayerNorm
+// statistics, its own 64 scores per head and the sample's K / V (precomputed once per call, step-invariant) -- so the three
+// launches of the unfused path (folded-LN to_q GEMM -> flash attention with Skv = 64 -> to_out GEMM + residual) move the
+// [M, C] tensor through HBM seven times (x, q, q, a, a, residual, y) for 129 GFLOP at level 0: 0.33 ms per transformer at
+// config-3 size, HBM- and latency-bound (the attention launch ran at 194 TFLOP/s).  Here x is read once (plus once more for the
+// residual, from L2) and y written once.
+//
+// Structure: 8 waves x 16 rows.  Everything is in the "swapped" MFMA orientation (weights / keys / values = A operand from LDS,
+// activations = B operand in registers), so each stage's accumulators ARE the next stage's B fragments -- lane (row l15, k-group
+// g) holds 4 k-values per 16-row source tile -- and nothing crosses lanes or LDS between the four chained products
+//   Q^T[64 x 16] = Wq'_h[64 x 320] X^T       S^T[64 keys x 16] = K_h Q^T       O^T[64 x 16] = V_h^T P^T       Y^T[320 x 16] += Wo_h O^T.
+// A B fragment built from two 16-row accumulator tiles presents its 8 k-values in the order [4g..4g+3 of tile 2c | of tile 2c+1],
+// not [8g..8g+7]: instead of permuting k inside 16-byte pieces (impossible for a DMA), the ROWS of the producing operand are
+// permuted -- LDS row rho = 16 t + 4 g + r holds natural row pi(rho) = 32 (t >> 1) + 8 g + 4 (t & 1) + r: Wq' rows once at weight
+// finalisation (with b', wsum), K_h rows (keys) and V_h^T rows (d) through the per-lane DMA source address -- so K, V^T and Wo
+// are read in their natural layouts.
+// Operands stream through LDS with global_load_lds (64-byte k-chunks, source-side XOR swizzle as gemm_wide.hip): per head
+// Wq'_h 40 KB (double-buffered), K_h + V_h^T 16 KB (double-buffered), Wo_h 40 KB (single: refilled while Q / S / PV of the same
+// head run); 156 KB of the 160 KB.  Two raw barriers per head, counted vmcnt waits.
+// LDS read traffic (every A fragment feeds ONE 16-column MFMA) co-limits with the MFMA pipe at ~50 %; the unfused path was at 15 %.
+//
+// Constraints (else the engine keeps the three-launch path): 16-bit engine, C = 320 (5 heads), 64 text tokens, HW % 128 == 0.
+#include "common.h"
+#include "gemm_device.h"
+#include "tuning.h"
+
+namespace tango {
+
+static constexpr int XA_C = 320, XA_HEADS = 5, XA_L = 64, XA_ROWS = 128;
+static constexpr int XA_WQ = 64 * 640;                 // bytes of one Wq'_h tile: 10 chunks x 64 rows x 64 B
+static constexpr int XA_WO = 2 * 320 * 64;             // Wo_h: 2 chunks x 320 rows x 64 B
+static constexpr int XA_KV = 2 * (2 * 64 * 64);        // K_h then V_h^T: 2 chunks x 64 rows x 64 B each
+static constexpr int XA_OFF_WQ = 0, XA_OFF_WO = 2 * XA_WQ, XA_OFF_KV = XA_OFF_WO + XA_WO, XA_OFF_CST = XA_OFF_KV + 2 * XA_KV;
+static constexpr int XA_LDS = XA_OFF_CST + 4096;       // consts: bq'[320] | wsum[320] | bo[320] | key bias[64] (fp32)
+
+__device__ __forceinline__ int xa_perm(int rho) {      // LDS row rho = 16 t + 4 g + r  ->  natural row 32 (t >> 1) + 8 g + 4 (t & 1) + r
+  const int t = rho >> 4, g = (rho >> 2) & 3, r = rho & 3;
+  return 32 * (t >> 1) + 8 * g + 4 * (t & 1) + r;
+}
+
+template <typename T> __device__ __forceinline__ u32x4 xa_pack8(const f32x4& a, const f32x4& b) {
+  T e[8];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { e[r] = from_f<T>(a[r]); e[4 + r] = from_f<T>(b[r]); }
+  u32x4 v;
+  __builtin_memcpy(&v, e, 16);
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void xattn_block_kernel(const XAttnParams p) {
+  constexpr int CB = 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int lrow = lane >> 2;                                        // DMA: row within a 16-row group, 16-byte slot lane & 3
+  const int dpc = ((lane & 3) ^ ((4 - (lrow >> 2)) & 3)) * 16;       // source piece of this lane's slot (gemm_wide.hip swizzle)
+  const int foff = l15 * CB + ((g ^ ((4 - (l15 >> 2)) & 3)) * 16);   // fragment read: row l15 of a 16-row group, k-group g
+  const int m0 = blockIdx.x * XA_ROWS;
+  const int b = m0 / p.HW;                                           // all 128 rows belong to one sample (HW % 128 == 0)
+  const unsigned char* const Xb = (const unsigned char*)p.x;
+  const unsigned char* const Wq = (const unsigned char*)p.wq;
+  const unsigned char* const Wo = (const unsigned char*)p.wo;
+  const unsigned char* const Kb = (const unsigned char*)p.k + (int64_t)b * XA_L * p.ldk * 2;
+  const unsigned char* const Vb = (const unsigned char*)p.vt + (int64_t)b * XA_C * p.ldvt * 2;
+  float* const cst = (float*)(dsm + XA_OFF_CST);
+
+  // ---- DMA issue helpers (each: this wave's share; identical instruction counts on every wave) ----
+  auto issue_wq = [&](const int h, const int buf) {                  // 40 x 1 KiB: e = wave + 8 i -> chunk e >> 2, row group e & 3
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int e = wave + 8 * i, c = e >> 2, rg = e & 3;
+      const unsigned char* src = Wq + ((int64_t)(h * 64 + rg * 16 + lrow) * XA_C + c * 32) * 2 + dpc;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dsm + XA_OFF_WQ + buf * XA_WQ + c * (64 * CB) + rg * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_wo = [&](const int h) {                                 // 40 x 1 KiB: e -> chunk e / 20, row group e % 20
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int e = wave + 8 * i, c = e / 20, rg = e - c * 20;
+      const unsigned char* src = Wo + ((int64_t)(rg * 16 + lrow) * p.ldwo + h * 64 + c * 32) * 2 + dpc;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dsm + XA_OFF_WO + c * (320 * CB) + rg * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_kv = [&](const int h, const int buf) {                  // 16 x 1 KiB: e = 2 wave + i; e < 8: K_h (rows = permuted keys), else V_h^T (rows = permuted d)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = 2 * wave + i, isv = e >> 3, c = (e >> 2) & 1, rg = e & 3;
+      const int nat = xa_perm(rg * 16 + lrow);
+      const unsigned char* src = isv ? Vb + ((int64_t)(h * 64 + nat) * p.ldvt + c * 32) * 2 + dpc
+                                     : Kb + ((int64_t)nat * p.ldk + h * 64 + c * 32) * 2 + dpc;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dsm + XA_OFF_KV + buf * XA_KV + isv * (2 * 64 * CB) + c * (64 * CB) + rg * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- prologue: first operands in flight, constants to LDS, this wave's 16 rows of x into B fragments + LayerNorm statistics ----
+  issue_wq(0, 0);
+  issue_kv(0, 0);
+  for (int i = tid; i < 1024; i += 512) {
+    float v;
+    if (i < 320) v = p.bq[i];
+    else if (i < 640) v = p.wsum[i - 320];
+    else if (i < 960) v = p.bo[i - 640];
+    else v = (i - 960 < p.L) ? (p.bias ? p.bias[(int64_t)b * p.L + (i - 960)] * 1.4426950408889634f : 0.f) : -1.0e30f;
+    cst[i] = v;
+  }
+  const int row = m0 + wave * 16 + l15;
+  u32x4 xf[10];
+#pragma unroll
+  for (int ks = 0; ks < 10; ++ks) xf[ks] = *(const u32x4*)(Xb + ((int64_t)row * p.ldx + ks * 32 + g * 8) * 2);
+  float mean, rstd;
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) {
+      T e[8];
+      __builtin_memcpy(e, &xf[ks], 16);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += to_f(e[u]);
+    }
+    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+    mean = s * (1.0f / XA_C);
+    float q = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) {
+      T e[8];
+      __builtin_memcpy(e, &xf[ks], 16);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const float d = to_f(e[u]) - mean; q += d * d; }
+    }
+    q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+    rstd = rsqrtf(q * (1.0f / XA_C) + p.eps);
+  }
+  f32x4 yacc[20];
+#pragma unroll
+  for (int t = 0; t < 20; ++t) yacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float sc2 = p.scale * 1.4426950408889634f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // x fragments (compiler-counted anyway) and the first DMAs
+  __syncthreads();                                                   // constants + Wq'_0 + K_0 / V_0 visible to every wave
+
+#pragma unroll 1
+  for (int h = 0; h < XA_HEADS; ++h) {
+    const int buf = h & 1;
+    // WO, the other Wq' buffer and the other K / V buffer are free: every wave is past Y of head h-1 (barrier at the loop tail)
+    issue_wo(h);                                                     // 5 DMAs: needed before Y of THIS head
+    if (h + 1 < XA_HEADS) { issue_kv(h + 1, buf ^ 1); issue_wq(h + 1, buf ^ 1); }      // 2 + 5 DMAs: needed at the top of the next head
+
+    // ---- Q^T = Wq'_h X^T (folded LayerNorm) ----
+    const unsigned char* Wqs = dsm + XA_OFF_WQ + buf * XA_WQ;
+    f32x4 qacc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const u32x4 wf = *(const u32x4*)(Wqs + ks * (64 * CB) + t * (16 * CB) + foff);
+        Mma<T>::run(qacc[t], wf, xf[ks]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 bqv = *(const f32x4*)(cst + h * 64 + t * 16 + g * 4);
+      const f32x4 wsv = *(const f32x4*)(cst + 320 + h * 64 + t * 16 + g * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float tq;
+        asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(tq) : "v"(mean), "v"(wsv[r]), "v"(qacc[t][r]));   // acc - mean * wsum as ONE fma (linear_stream.hip race notes)
+        qacc[t][r] = rstd * tq + bqv[r];
+      }
+    }
+    u32x4 qb[2];
+    qb[0] = xa_pack8<T>(qacc[0], qacc[1]);
+    qb[1] = xa_pack8<T>(qacc[2], qacc[3]);
+
+    // ---- S^T = K_h Q^T ; softmax over the 64 keys (fp32, exp2 domain, additive -10000 mask bias as the reference) ----
+    const unsigned char* Ks = dsm + XA_OFF_KV + buf * XA_KV;
+    const unsigned char* Vs = Ks + 2 * 64 * CB;
+    f32x4 sacc[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) sacc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const u32x4 kf = *(const u32x4*)(Ks + c * (64 * CB) + kb * (16 * CB) + foff);
+        Mma<T>::run(sacc[kb], kf, qb[c]);
+      }
+    }
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const f32x4 bv = *(const f32x4*)(cst + 960 + 32 * (kb >> 1) + 8 * g + 4 * (kb & 1));      // natural keys of LDS rows 16 kb + 4 g + 0..3
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sv = __builtin_fmaf(sacc[kb][r], sc2, bv[r]);
+        sacc[kb][r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float ls = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] - mx);
+        sacc[kb][r] = pv;
+        ls += pv;
+      }
+    ls += __shfl_xor(ls, 16); ls += __shfl_xor(ls, 32);
+    const float inv = 1.0f / ls;
+    u32x4 pf[2];
+    pf[0] = xa_pack8<T>(sacc[0], sacc[1]);
+    pf[1] = xa_pack8<T>(sacc[2], sacc[3]);
+
+    // ---- O^T = V_h^T P^T ----
+    f32x4 oacc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) oacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const u32x4 vf = *(const u32x4*)(Vs + c * (64 * CB) + t * (16 * CB) + foff);
+        Mma<T>::run(oacc[t], vf, pf[c]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) oacc[t] *= inv;
+    u32x4 ob[2];
+    ob[0] = xa_pack8<T>(oacc[0], oacc[1]);
+    ob[1] = xa_pack8<T>(oacc[2], oacc[3]);
+
+    // ---- Y^T += Wo_h O^T : Wo_h must have landed (this wave's 5 DMAs are the OLDEST of the up to 12 it has in flight) ----
+    if (h + 1 < XA_HEADS) wait_vmcnt_lit<7>(); else wait_vmcnt_lit<0>();
+    pp_barrier();
+    const unsigned char* Wos = dsm + XA_OFF_WO;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int t = 0; t < 20; ++t) {
+        const u32x4 wf = *(const u32x4*)(Wos + c * (320 * CB) + t * (16 * CB) + foff);
+        Mma<T>::run(yacc[t], wf, ob[c]);
+      }
+    }
+    // next head's Wq' / K / V landed (this wave's share), then every wave is done with WO and this head's buffers
+    wait_vmcnt_lit<0>();
+    pp_barrier();
+  }
+
+  // ---- epilogue: y = Y + b_out + x, through per-wave fp32 staging (two halves of 160 channels) so that the residual reads and the
+  //      stores are whole 16-byte pieces of contiguous rows; one rounding to T ----
+  constexpr int PITCH = 160 * 4 + 16;
+  unsigned char* const stage = dsm + wave * (16 * PITCH);            // 8 x 10496 B inside the (now idle) Wq' / Wo buffers
+  T* const Ob = (T*)p.out;
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+    for (int tt = 0; tt < 10; ++tt) {
+      const int t = hf * 10 + tt;
+      const f32x4 bov = *(const f32x4*)(cst + 640 + t * 16 + g * 4);
+      *(f32x4*)(stage + l15 * PITCH + (tt * 16 + g * 4) * 4) = yacc[t] + bov;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {                                 // 16 rows x 20 pieces of 8 channels = 320 = 5 x 64 lanes
+      const int idx = lane + it * 64, rr = idx / 20, pcs = idx - rr * 20;
+      const int64_t grow = (int64_t)(m0 + wave * 16 + rr);
+      const f32x4 lo = *(const f32x4*)(stage + rr * PITCH + pcs * 32);
+      const f32x4 hi = *(const f32x4*)(stage + rr * PITCH + pcs * 32 + 16);
+      const u32x4 rv = *(const u32x4*)(Xb + (grow * p.ldx + hf * 160 + pcs * 8) * 2);
+      T r8[8], o8[8];
+      __builtin_memcpy(r8, &rv, 16);
+      const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) o8[u] = from_f<T>(f[u] + to_f(r8[u]));
+      u32x4 ov;
+      __builtin_memcpy(&ov, o8, 16);
+      *(u32x4*)(Ob + grow * p.ldo + hf * 160 + pcs * 8) = ov;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// rows of one head's 64-row block permuted for the chained-MFMA layout (see the header): dst row h*64 + rho <- src row h*64 + pi(rho)
+template <typename T>
+__global__ __launch_bounds__(256) void xattn_permute_wq_kernel(const T* __restrict__ W, const float* __restrict__ b, const float* __restrict__ ws,
+                                                               T* __restrict__ Wp, float* __restrict__ bp, float* __restrict__ wsp, int C) {
+  const int n = blockIdx.x;                                          // destination row
+  const int h = n >> 6, rho = n & 63;
+  const int t = rho >> 4, gg = (rho >> 2) & 3, r = rho & 3;
+  const int src = h * 64 + 32 * (t >> 1) + 8 * gg + 4 * (t & 1) + r;
+  for (int k = threadIdx.x; k < C; k += 256) Wp[(int64_t)n * C + k] = W[(int64_t)src * C + k];
+  if (threadIdx.x == 0) { bp[n] = b ? b[src] : 0.f; wsp[n] = ws[src]; }
+}
+
+int launch_xattn_permute_wq(int dtype, const void* W, const float* b, const float* wsum, void* Wp, float* bp, float* wsp, int C, hipStream_t s) {
+  if (dtype == DT_F16) hipLaunchKernelGGL((xattn_permute_wq_kernel<f16>), dim3((unsigned)C), dim3(256), 0, s, (const f16*)W, b, wsum, (f16*)Wp, bp, wsp, C);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL((xattn_permute_wq_kernel<bf16>), dim3((unsigned)C), dim3(256), 0, s, (const bf16*)W, b, wsum, (bf16*)Wp, bp, wsp, C);
+  else TANGO_FAIL("xattn: 16-bit dtypes only");
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+bool xattn_block_ok(int dtype, int C, int heads, int HW, int L, int64_t ldx, int64_t ldo, int64_t ldk, int64_t ldvt) {
+  if (tuning().no_xattn_fused || dtype == DT_F32) return false;
+  if (C != XA_C || heads != XA_HEADS || L != XA_L || HW % XA_ROWS != 0) return false;
+  return ldx % 8 == 0 && ldo % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0;
+}
+
+int launch_xattn_block(int dtype, const XAttnParams& p, hipStream_t s) {
+  if (p.M % XA_ROWS != 0) TANGO_FAIL("xattn: M must be a multiple of 128");
+  if (((uintptr_t)p.x | (uintptr_t)p.out | (uintptr_t)p.wq | (uintptr_t)p.wo | (uintptr_t)p.k | (uintptr_t)p.vt) & 15) TANGO_FAIL("xattn: 16-byte alignment");
+  const unsigned grid = (unsigned)(p.M / XA_ROWS);
+  if (dtype == DT_F16) {
+    static bool attr = false;
+    if (!attr) { TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_block_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS)); attr = true; }
+    hipLaunchKernelGGL((xattn_block_kernel<f16>), dim3(grid), dim3(512), XA_LDS, s, p);
+  } else if (dtype == DT_BF16) {
+    static bool attr = false;
+    if (!attr) { TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_block_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS)); attr = true; }
+    hipLaunchKernelGGL((xattn_block_kernel<bf16>), dim3(grid), dim3(512), XA_LDS, s, p);
+  } else {
+    TANGO_FAIL("xattn: 16-bit dtypes only");
+  }
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace tango

@@ -1,0 +1,112 @@
+"""Fused cross-attention block (xattn.hip, round 3): norm2 -> attn2 (to_q, softmax(Q K^T / 8 + mask) V over the 64 text tokens,
+to_out) -> + residual of BasicTransformerBlock (diffusers attention.py:312-323; attention_processor.py:495-540) in one launch,
+against the torch statement of the same block.  Also: engine plans with and without the fused kernel agree (TANGO_NO_XATTN_FUSED is
+read once per process, so that comparison runs in a subprocess), and repeat-run determinism."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = {"fp16": (1, 4e-3), "bf16": (2, 3e-2)}
+
+
+def q16(t, dtype):
+    return t.half().float() if dtype == "fp16" else t.bfloat16().float()
+
+
+def reference(x, ga, be, wq, k, v, bias, wo, bo, B, HW, L):
+    C_ = 320
+    xn = F.layer_norm(x, (C_,), ga, be, 1e-5)
+    q = (xn @ wq.t()).view(B, HW, 5, 64).transpose(1, 2)
+    kh = k.view(B, L, 5, 64).transpose(1, 2)
+    vh = v.view(B, L, 5, 64).transpose(1, 2)
+    s = q @ kh.transpose(-1, -2) * 0.125
+    if bias is not None:
+        s = s + bias[:, None, None, :]
+    a = (s.softmax(-1) @ vh).transpose(1, 2).reshape(B * HW, C_)
+    return x + a @ wo.t() + bo
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,HW,masked", [(2, 256, True), (3, 128, False), (2, 4096, True)])
+def test_xattn_block(lib, dtype, B, HW, masked):
+    code, tol = DT[dtype]
+    g = torch.Generator().manual_seed(B * 1000 + HW)
+    L, C_ = 64, 320
+    x = q16(torch.randn(B * HW, C_, generator=g) * 1.3 + 0.4, dtype)
+    ga, be = 1 + 0.2 * torch.randn(C_, generator=g), 0.3 * torch.randn(C_, generator=g)
+    wq = q16(torch.randn(C_, C_, generator=g) / C_ ** 0.5, dtype)
+    wo = q16(torch.randn(C_, C_, generator=g) / C_ ** 0.5, dtype)
+    bo = torch.randn(C_, generator=g)
+    k = q16(torch.randn(B * L, C_, generator=g), dtype)
+    v = q16(torch.randn(B * L, C_, generator=g), dtype)
+    bias = None
+    if masked:
+        m = torch.ones(B, L)
+        m[0, 1:] = 0                                  # the T5("") row: one live key
+        m[1, 37:] = 0
+        bias = (1 - m) * -10000.0
+    ref = reference(x, ga, be, wq, k, v, bias, wo, bo, B, HW, L)
+    dev = lambda t: t.cuda().contiguous() if t is not None else None   # noqa: E731
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+    xd, gad, bed, wqd, kd, vd, bd, wod, bod = (dev(t) for t in (x, ga, be, wq, k, v, bias, wo, bo))
+    out = torch.zeros(B * HW, C_, device="cuda")
+    first = None
+    for rep in range(20):
+        rc = lib.tango_op_xattn_block(code, p(xd), p(gad), p(bed), p(wqd), p(kd), p(vd), p(bd), p(wod), p(bod), p(out), B, HW, L, 1e-5, None)
+        assert rc == 0, lib.tango_last_error().decode()
+        if first is None:
+            first = out.clone()
+        else:
+            assert torch.equal(out, first), "repetition %d differs" % rep
+    err = ((first.cpu() - ref).abs().max() / ref.abs().max()).item()
+    # the attention branch alone (what the kernel adds to x): a wrong branch must not hide behind the residual
+    berr = (((first.cpu() - x) - (ref - x)).abs().max() / (ref - x).abs().max()).item()
+    print("xattn block %s B=%d HW=%d masked=%s: rel err %.3e (branch only %.3e)" % (dtype, B, HW, masked, err, berr))
+    assert err <= tol and berr <= 4 * tol
+
+
+def test_xattn_block_rejects_other_shapes(lib):
+    x = torch.zeros(128, 320, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    assert lib.tango_op_xattn_block(0, p(x), p(x), p(x), p(x), p(x), p(x), None, p(x), p(x), p(x), 1, 128, 64, 1e-5, None) != 0   # fp32
+    assert lib.tango_op_xattn_block(1, p(x), p(x), p(x), p(x), p(x), p(x), None, p(x), p(x), p(x), 1, 128, 48, 1e-5, None) != 0   # L != 64
+    assert lib.tango_op_xattn_block(1, p(x), p(x), p(x), p(x), p(x), p(x), None, p(x), p(x), p(x), 1, 64, 64, 1e-5, None) != 0    # HW % 128
+
+
+_AB = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from oracle import tango_oracle as O
+from tango_amd.engine import Engine
+cfg = O.UNET_CONFIG_LARGE
+e = Engine(unet=cfg, dtype="fp16"); e.load_synthetic(1234)
+g = torch.Generator().manual_seed(77)
+x = torch.randn(4, 8, 256, 16, generator=g); enc = torch.randn(4, 64, 1024, generator=g)
+mask = torch.ones(4, 64, dtype=torch.bool); mask[:2, 1:] = False
+labels = [r[0] for r in e.profile_unet(4, 64)]
+out = e.unet_forward(x.cuda(), 500, enc.cuda(), mask.cuda()).cpu()
+torch.save({"out": out, "fused": sum("xattn_block" in l for l in labels)}, sys.argv[1])
+'''
+
+
+def test_unet_with_and_without_fused_xattn(tmp_path):
+    """the same full-size fp16 UNet forward with the fused block (5 level-0 transformers) and with TANGO_NO_XATTN_FUSED=1"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, env in (("fused", {}), ("unfused", {"TANGO_NO_XATTN_FUSED": "1"})):
+        f = str(tmp_path / (name + ".pt"))
+        r = subprocess.run([sys.executable, "-c", _AB % root, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = torch.load(f)
+    assert outs["fused"]["fused"] == 5 and outs["unfused"]["fused"] == 0
+    a, b = outs["fused"]["out"], outs["unfused"]["out"]
+    d = ((a - b).abs().max() / b.abs().max()).item()
+    print("full-size fp16 UNet forward, fused vs three-launch cross-attention: rel diff %.3e" % d)
+    assert d <= 5e-3
