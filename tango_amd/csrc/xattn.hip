@@ -165,6 +165,13 @@ __global__ __launch_bounds__(512) void xattn_block_kernel(const XAttnParams p) {
         Mma<T>::run(qacc[t], wf, xf[ks]);
       }
     }
+    // The folded-LN form below reads the accumulators from INLINE ASM.  hipcc pads MFMA -> VALU read hazards only for instructions
+    // it models; an asm operand is not one of them (cdna_hip_programming.md 5.7 item 2), and here -- unlike the epilogues of
+    // gemm_wide.hip / linear_stream.hip, where hundreds of instructions separate the two -- the last Q MFMA is a few slots away
+    // (first version: outputs differed between repetitions).  24 wait states cover the 8-pass XDL write -> VALU read distance.
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const f32x4 bqv = *(const f32x4*)(cst + h * 64 + t * 16 + g * 4);

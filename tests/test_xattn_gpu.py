@@ -63,8 +63,12 @@ def test_xattn_block(lib, dtype, B, HW, masked):
         assert rc == 0, lib.tango_last_error().decode()
         if first is None:
             first = out.clone()
-        else:
-            assert torch.equal(out, first), "repetition %d differs" % rep
+        elif not torch.equal(out, first):
+            bad = (out != first).nonzero()
+            rows, cols = bad[:, 0].unique(), bad[:, 1].unique()
+            raise AssertionError("repetition %d differs at %d elements: rows %s (%d distinct; mod 16: %s), cols %s (%d distinct); max |diff| %.3e"
+                                 % (rep, bad.shape[0], rows[:12].tolist(), rows.numel(), sorted(set((rows % 16).tolist()))[:16], cols[:12].tolist(),
+                                    cols.numel(), (out - first).abs().max().item()))
     err = ((first.cpu() - ref).abs().max() / ref.abs().max()).item()
     # the attention branch alone (what the kernel adds to x): a wrong branch must not hide behind the residual
     berr = (((first.cpu() - x) - (ref - x)).abs().max() / (ref - x).abs().max()).item()
