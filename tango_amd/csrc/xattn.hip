@@ -8,8 +8,8 @@
 // statistics, its own 64 scores per head and the sample's K / V (precomputed once per call, step-invariant) -- so the three
 // launches of the unfused path (folded-LN to_q GEMM -> flash attention with Skv = 64 -> to_out GEMM + residual) move the
 // [M, C] tensor through HBM seven times (x, q, q, a, a, residual, y) for 129 GFLOP at level 0: 0.33 ms per transformer at
-// config-3 size, HBM- and latency-bound (the attention launch ran at 194 TFLOP/s).  Here x is read once (plus once more for the
-// residual, from L2) and y written once.
+// config-3 size, HBM- and latency-bound (the attention launch ran at 194 TFLOP/s).  Here x is read once (the residual is added from
+// the same registers, through LDS) and y written once.
 //
 // Structure: 8 waves x 16 rows.  Everything is in the "swapped" MFMA orientation (weights / keys / values = A operand from LDS,
 // activations = B operand in registers), so each stage's accumulators ARE the next stage's B fragments -- lane (row l15, k-group
@@ -23,15 +23,20 @@
 // Operands stream through LDS with global_load_lds (64-byte k-chunks, source-side XOR swizzle as gemm_wide.hip): per head
 // Wq'_h 40 KB (double-buffered), K_h + V_h^T 16 KB (double-buffered), Wo_h 40 KB (single: refilled while Q / S / PV of the same
 // head run); 156 KB of the 160 KB.  Two raw barriers per head, counted vmcnt waits.
-// LDS read traffic (every A fragment feeds ONE 16-column MFMA) co-limits with the MFMA pipe at ~50 %; the unfused path was at 15 %.
+// Every A fragment feeds ONE 16-column MFMA, so the LDS read port (1 KiB per 16 MFMA cycles per wave) is the co-limit of the
+// four products; measured by compiling parts out (profiles/r3_c8_xattn_ablation.txt, 243 us per launch at config-3 size): the two
+// 40-fragment streams 54 us, the epilogue 58 us (HBM: it re-read the residual then), prologue + softmax chain ~100 us, DMA waits
+// and barriers ~30 us -- with one workgroup per CU (156 KiB of LDS) the HBM phases and the MFMA phases of a tile do not overlap.
 //
 // Constraints (else the engine keeps the three-launch path): 16-bit engine, C = 320 (5 heads), 64 text tokens, HW % 128 == 0.
 #include "common.h"
 #include "gemm_device.h"
 #include "tuning.h"
+#include <type_traits>
 
 namespace tango {
 
+static constexpr int XA_DEPTH = 4;                       // LDS fragment reads in flight per stream (2 / 4 / 8 measured: 1.20 / 1.16 / 1.18 ms per step)
 static constexpr int XA_C = 320, XA_HEADS = 5, XA_L = 64, XA_ROWS = 128;
 static constexpr int XA_WQ = 64 * 640;                 // bytes of one Wq'_h tile: 10 chunks x 64 rows x 64 B
 static constexpr int XA_WO = 2 * 320 * 64;             // Wo_h: 2 chunks x 320 rows x 64 B
@@ -52,6 +57,57 @@ template <typename T> __device__ __forceinline__ u32x4 xa_pack8(const f32x4& a, 
   __builtin_memcpy(&v, e, 16);
   return v;
 }
+
+
+// sum over the four lanes {l, l^16, l^32, l^48} without the LDS crossbar (attention.hip quad_max: same swaps; the add is inline
+// asm for the same two hipcc reasons)
+__device__ __forceinline__ float xa_asm_max(float a, float b) { float m; asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b)); return m; }
+__device__ __forceinline__ float xa_asm_add(float a, float b) { float m; asm("v_add_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b)); return m; }
+template <bool MAX> __device__ __forceinline__ float xa_quad_reduce(float v) {
+  const unsigned a = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+  const float r0 = __builtin_bit_cast(float, (unsigned)r[0]), r1 = __builtin_bit_cast(float, (unsigned)r[1]);
+  const float m = MAX ? xa_asm_max(r0, r1) : xa_asm_add(r0, r1);
+  const unsigned c = __builtin_bit_cast(unsigned, m);
+  const auto q = __builtin_amdgcn_permlane16_swap(c, c, false, false);
+  const float q0 = __builtin_bit_cast(float, (unsigned)q[0]), q1 = __builtin_bit_cast(float, (unsigned)q[1]);
+  return MAX ? xa_asm_max(q0, q1) : xa_asm_add(q0, q1);
+}
+
+// LDS fragment reads the compiler does not track.  While global_load_lds operations are pending hipcc waits lgkmcnt(0) before
+// every use of a ds_read result (it models the LDS DMA as a FLAT access that may complete out of order with LDS reads), so a
+// compiler-scheduled fragment stream exposes one full LDS round trip per MFMA group -- the first version of this kernel spent
+// ~3/4 of its time there (48 exposed latencies per head).  The DMA is counted by vmcnt only and LDS reads return in order, so
+// counted waits are correct: xa_lds_read issues the read from inline asm, xa_lds_wait<N> waits until at most N reads are
+// outstanding and ties the fragment to the wait (so no consumer can be scheduled above it).
+template <int OFF> __device__ __forceinline__ u32x4 xa_lds_read(const unsigned base) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(OFF));
+  return v;
+}
+template <int N> __device__ __forceinline__ void xa_lds_wait(u32x4& frag) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N)); }
+__device__ __forceinline__ unsigned xa_lds_addr(const unsigned char* p) { return (unsigned)(uintptr_t)(lptr_t)p; }
+
+// compile-time index loop (fragment offsets must be immediates)
+template <int I, int N, typename F> __device__ __forceinline__ void xa_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); xa_for<I + 1, N>(f); }
+}
+
+// N A-fragments (LDS byte offset OFF(i) from `base`) streamed with D reads in flight ahead of the MFMA that consumes them
+template <int N, int D, typename OFF, typename MM> __device__ __forceinline__ void xa_stream(const unsigned base, OFF, MM&& mm) {
+  u32x4 ring[D];
+  xa_for<0, D>([&](auto i) { ring[i] = xa_lds_read<OFF::at(i)>(base); });
+  xa_for<0, N>([&](auto i) {
+    constexpr int after = (N - 1 - i) < (D - 1) ? (N - 1 - i) : (D - 1);      // reads issued after fragment i at this point
+    xa_lds_wait<after>(ring[i % D]);
+    mm(i, ring[i % D]);
+    if constexpr (i + D < N) ring[i % D] = xa_lds_read<OFF::at(i + D)>(base);
+    __builtin_amdgcn_sched_barrier(0);                               // keep read / MFMA alternation as written
+  });
+}
+struct XaOffQ { static constexpr int at(int i) { return (i >> 2) * (64 * 64) + (i & 3) * (16 * 64); } };    // Wq'_h: chunk i >> 2, row group i & 3
+struct XaOffY { static constexpr int at(int i) { return (i / 20) * (320 * 64) + (i % 20) * (16 * 64); } };  // Wo_h: chunk i / 20, row group i % 20
+struct XaOffKV { static constexpr int at(int i) { return (i >> 2) * (64 * 64) + (i & 3) * (16 * 64); } };   // K_h / V_h^T: 2 chunks x 4 row groups
 
 template <typename T>
 __global__ __launch_bounds__(512) void xattn_block_kernel(const XAttnParams p) {
@@ -100,21 +156,25 @@ __global__ __launch_bounds__(512) void xattn_block_kernel(const XAttnParams p) {
     }
   };
 
-  // ---- prologue: first operands in flight, constants to LDS, this wave's 16 rows of x into B fragments + LayerNorm statistics ----
-  issue_wq(0, 0);
-  issue_kv(0, 0);
-  for (int i = tid; i < 1024; i += 512) {
-    float v;
-    if (i < 320) v = p.bq[i];
-    else if (i < 640) v = p.wsum[i - 320];
-    else if (i < 960) v = p.bo[i - 640];
-    else v = (i - 960 < p.L) ? (p.bias ? p.bias[(int64_t)b * p.L + (i - 960)] * 1.4426950408889634f : 0.f) : -1.0e30f;
-    cst[i] = v;
-  }
+  // ---- prologue: ONE memory round trip -- this wave's 16 rows of x (HBM, the longest latency) first, then the first operand DMAs,
+  //      then the constants as two unconditional loads per thread (the first version looped with a load -> wait -> ds_write chain
+  //      per iteration ahead of the x loads: three serialized latencies per workgroup, and there is only one workgroup per CU) ----
   const int row = m0 + wave * 16 + l15;
   u32x4 xf[10];
 #pragma unroll
   for (int ks = 0; ks < 10; ++ks) xf[ks] = *(const u32x4*)(Xb + ((int64_t)row * p.ldx + ks * 32 + g * 8) * 2);
+  issue_wq(0, 0);
+  issue_kv(0, 0);
+  {
+    const int i1 = tid + 512;                                        // cst[tid]: bq | wsum[0..191] ; cst[i1]: wsum[192..319] | bo | key bias
+    const float* const s0 = tid < 320 ? p.bq + tid : p.wsum + (tid - 320);
+    const bool isb = i1 >= 960, live = isb && (i1 - 960) < p.L && p.bias != nullptr;
+    const float* const s1 = i1 < 640 ? p.wsum + (i1 - 320) : !isb ? p.bo + (i1 - 640) : live ? p.bias + (int64_t)b * p.L + (i1 - 960) : p.bo;
+    const float v0 = *s0, v1r = *s1;
+    const float v1 = !isb ? v1r : (i1 - 960) < p.L ? (live ? v1r * 1.4426950408889634f : 0.f) : -1.0e30f;
+    cst[tid] = v0;
+    cst[i1] = v1;
+  }
   float mean, rstd;
   {
     float s = 0.f;
@@ -157,14 +217,18 @@ __global__ __launch_bounds__(512) void xattn_block_kernel(const XAttnParams p) {
     f32x4 qacc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) qacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    xa_stream<40, XA_DEPTH>(xa_lds_addr(Wqs + foff), XaOffQ{}, [&](const int i, const u32x4& wf) { Mma<T>::run(qacc[i & 3], wf, xf[i >> 2]); });
+    // K_h fragments and this head's bias / wsum constants: issued now, landing under the hazard padding and the Q epilogue
+    const unsigned char* Ks = dsm + XA_OFF_KV + buf * XA_KV;
+    const unsigned char* Vs = Ks + 2 * 64 * CB;
+    f32x4 bqv[4], wsv[4];
 #pragma unroll
-    for (int ks = 0; ks < 10; ++ks) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const u32x4 wf = *(const u32x4*)(Wqs + ks * (64 * CB) + t * (16 * CB) + foff);
-        Mma<T>::run(qacc[t], wf, xf[ks]);
-      }
+    for (int t = 0; t < 4; ++t) {
+      bqv[t] = *(const f32x4*)(cst + h * 64 + t * 16 + g * 4);
+      wsv[t] = *(const f32x4*)(cst + 320 + h * 64 + t * 16 + g * 4);
     }
+    u32x4 kf[8];
+    xa_for<0, 8>([&](auto i) { kf[i] = xa_lds_read<XaOffKV::at(i)>(xa_lds_addr(Ks + foff)); });
     // The folded-LN form below reads the accumulators from INLINE ASM.  hipcc pads MFMA -> VALU read hazards only for instructions
     // it models; an asm operand is not one of them (cdna_hip_programming.md 5.7 item 2), and here -- unlike the epilogues of
     // gemm_wide.hip / linear_stream.hip, where hundreds of instructions separate the two -- the last Q MFMA is a few slots away
@@ -174,13 +238,11 @@ __global__ __launch_bounds__(512) void xattn_block_kernel(const XAttnParams p) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const f32x4 bqv = *(const f32x4*)(cst + h * 64 + t * 16 + g * 4);
-      const f32x4 wsv = *(const f32x4*)(cst + 320 + h * 64 + t * 16 + g * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float tq;
-        asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(tq) : "v"(mean), "v"(wsv[r]), "v"(qacc[t][r]));   // acc - mean * wsum as ONE fma (linear_stream.hip race notes)
-        qacc[t][r] = rstd * tq + bqv[r];
+        asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(tq) : "v"(mean), "v"(wsv[t][r]), "v"(qacc[t][r]));   // acc - mean * wsum as ONE fma (linear_stream.hip race notes)
+        qacc[t][r] = rstd * tq + bqv[t][r];
       }
     }
     u32x4 qb[2];
@@ -188,23 +250,20 @@ __global__ __launch_bounds__(512) void xattn_block_kernel(const XAttnParams p) {
     qb[1] = xa_pack8<T>(qacc[2], qacc[3]);
 
     // ---- S^T = K_h Q^T ; softmax over the 64 keys (fp32, exp2 domain, additive -10000 mask bias as the reference) ----
-    const unsigned char* Ks = dsm + XA_OFF_KV + buf * XA_KV;
-    const unsigned char* Vs = Ks + 2 * 64 * CB;
     f32x4 sacc[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) sacc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    xa_for<0, 8>([&](auto i) { xa_lds_wait<0>(kf[i]); Mma<T>::run(sacc[i & 3], kf[i], qb[i >> 2]); });
+    u32x4 vf[8];                                                     // V_h^T fragments: in flight under the softmax
+    xa_for<0, 8>([&](auto i) { vf[i] = xa_lds_read<XaOffKV::at(i)>(xa_lds_addr(Vs + foff)); });
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 kbias[4];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const u32x4 kf = *(const u32x4*)(Ks + c * (64 * CB) + kb * (16 * CB) + foff);
-        Mma<T>::run(sacc[kb], kf, qb[c]);
-      }
-    }
+    for (int kb = 0; kb < 4; ++kb) kbias[kb] = *(const f32x4*)(cst + 960 + 32 * (kb >> 1) + 8 * g + 4 * (kb & 1));   // natural keys of LDS rows 16 kb + 4 g + 0..3
     float mx = -3.0e38f;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      const f32x4 bv = *(const f32x4*)(cst + 960 + 32 * (kb >> 1) + 8 * g + 4 * (kb & 1));      // natural keys of LDS rows 16 kb + 4 g + 0..3
+      const f32x4 bv = kbias[kb];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float sv = __builtin_fmaf(sacc[kb][r], sc2, bv[r]);
@@ -212,7 +271,7 @@ __global__ __launch_bounds__(512) void xattn_block_kernel(const XAttnParams p) {
         mx = fmaxf(mx, sv);
       }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = xa_quad_reduce<true>(mx);
     float ls = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
@@ -222,7 +281,7 @@ __global__ __launch_bounds__(512) void xattn_block_kernel(const XAttnParams p) {
         sacc[kb][r] = pv;
         ls += pv;
       }
-    ls += __shfl_xor(ls, 16); ls += __shfl_xor(ls, 32);
+    ls = xa_quad_reduce<false>(ls);
     const float inv = 1.0f / ls;
     u32x4 pf[2];
     pf[0] = xa_pack8<T>(sacc[0], sacc[1]);
@@ -232,14 +291,7 @@ __global__ __launch_bounds__(512) void xattn_block_kernel(const XAttnParams p) {
     f32x4 oacc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) oacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const u32x4 vf = *(const u32x4*)(Vs + c * (64 * CB) + t * (16 * CB) + foff);
-        Mma<T>::run(oacc[t], vf, pf[c]);
-      }
-    }
+    xa_for<0, 8>([&](auto i) { xa_lds_wait<0>(vf[i]); Mma<T>::run(oacc[i & 3], vf[i], pf[i >> 2]); });
 #pragma unroll
     for (int t = 0; t < 4; ++t) oacc[t] *= inv;
     u32x4 ob[2];
@@ -250,14 +302,7 @@ __global__ __launch_bounds__(512) void xattn_block_kernel(const XAttnParams p) {
     if (h + 1 < XA_HEADS) wait_vmcnt_lit<7>(); else wait_vmcnt_lit<0>();
     pp_barrier();
     const unsigned char* Wos = dsm + XA_OFF_WO;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-#pragma unroll
-      for (int t = 0; t < 20; ++t) {
-        const u32x4 wf = *(const u32x4*)(Wos + c * (320 * CB) + t * (16 * CB) + foff);
-        Mma<T>::run(yacc[t], wf, ob[c]);
-      }
-    }
+    xa_stream<40, XA_DEPTH>(xa_lds_addr(Wos + foff), XaOffY{}, [&](const int i, const u32x4& wf) { Mma<T>::run(yacc[i % 20], wf, ob[i / 20]); });
     // next head's Wq' / K / V landed (this wave's share), then every wave is done with WO and this head's buffers
     wait_vmcnt_lit<0>();
     pp_barrier();
@@ -265,8 +310,9 @@ __global__ __launch_bounds__(512) void xattn_block_kernel(const XAttnParams p) {
 
   // ---- epilogue: y = Y + b_out + x, through per-wave fp32 staging (two halves of 160 channels) so that the residual reads and the
   //      stores are whole 16-byte pieces of contiguous rows; one rounding to T ----
-  constexpr int PITCH = 160 * 4 + 16;
-  unsigned char* const stage = dsm + wave * (16 * PITCH);            // 8 x 10496 B inside the (now idle) Wq' / Wo buffers
+  constexpr int PITCH = 160 * 4 + 16, XPITCH = 160 * 2 + 16;
+  unsigned char* const stage = dsm + wave * (16 * (PITCH + XPITCH)); // 8 x 15872 B inside the (now idle) Wq' / Wo buffers
+  unsigned char* const xstage = stage + 16 * PITCH;                  // this wave's 16 rows of x (the residual), from the B fragments: x is read from HBM once
   T* const Ob = (T*)p.out;
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf) {
@@ -276,6 +322,8 @@ __global__ __launch_bounds__(512) void xattn_block_kernel(const XAttnParams p) {
       const f32x4 bov = *(const f32x4*)(cst + 640 + t * 16 + g * 4);
       *(f32x4*)(stage + l15 * PITCH + (tt * 16 + g * 4) * 4) = yacc[t] + bov;
     }
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) *(u32x4*)(xstage + l15 * XPITCH + (kk * 32 + g * 8) * 2) = xf[hf * 5 + kk];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int it = 0; it < 5; ++it) {                                 // 16 rows x 20 pieces of 8 channels = 320 = 5 x 64 lanes
@@ -283,7 +331,7 @@ __global__ __launch_bounds__(512) void xattn_block_kernel(const XAttnParams p) {
       const int64_t grow = (int64_t)(m0 + wave * 16 + rr);
       const f32x4 lo = *(const f32x4*)(stage + rr * PITCH + pcs * 32);
       const f32x4 hi = *(const f32x4*)(stage + rr * PITCH + pcs * 32 + 16);
-      const u32x4 rv = *(const u32x4*)(Xb + (grow * p.ldx + hf * 160 + pcs * 8) * 2);
+      const u32x4 rv = *(const u32x4*)(xstage + rr * XPITCH + pcs * 16);
       T r8[8], o8[8];
       __builtin_memcpy(r8, &rv, 16);
       const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -323,23 +371,21 @@ bool xattn_block_ok(int dtype, int C, int heads, int HW, int L, int64_t ldx, int
   return ldx % 8 == 0 && ldo % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0;
 }
 
+template <typename T> static int xa_launch(const XAttnParams& p, unsigned grid, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) { TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_block_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS)); attr = true; }
+  hipLaunchKernelGGL((xattn_block_kernel<T>), dim3(grid), dim3(512), XA_LDS, s, p);
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_xattn_block(int dtype, const XAttnParams& p, hipStream_t s) {
   if (p.M % XA_ROWS != 0) TANGO_FAIL("xattn: M must be a multiple of 128");
   if (((uintptr_t)p.x | (uintptr_t)p.out | (uintptr_t)p.wq | (uintptr_t)p.wo | (uintptr_t)p.k | (uintptr_t)p.vt) & 15) TANGO_FAIL("xattn: 16-byte alignment");
   const unsigned grid = (unsigned)(p.M / XA_ROWS);
-  if (dtype == DT_F16) {
-    static bool attr = false;
-    if (!attr) { TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_block_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS)); attr = true; }
-    hipLaunchKernelGGL((xattn_block_kernel<f16>), dim3(grid), dim3(512), XA_LDS, s, p);
-  } else if (dtype == DT_BF16) {
-    static bool attr = false;
-    if (!attr) { TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_block_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS)); attr = true; }
-    hipLaunchKernelGGL((xattn_block_kernel<bf16>), dim3(grid), dim3(512), XA_LDS, s, p);
-  } else {
-    TANGO_FAIL("xattn: 16-bit dtypes only");
-  }
-  TANGO_HIP(hipGetLastError());
-  return 0;
+  if (dtype == DT_F16) return xa_launch<f16>(p, grid, s);
+  if (dtype == DT_BF16) return xa_launch<bf16>(p, grid, s);
+  TANGO_FAIL("xattn: 16-bit dtypes only");
 }
 
 }  // namespace tango
