@@ -239,8 +239,8 @@ def main():
             "value": audio_s / dt, "unit": "audio-seconds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic (seeded random weights of the real architecture; N(0,1) text embeddings)",
-            "config": {"workload": "%s: Tango-full%s UNet (866M) %d-step DDPM CFG=%g denoise%s + mel-VAE decode + "
-                                   "HiFi-GAN, %d prompts/GPU x %d tokens" % (workload_name(args), " XL" if args.xl else "", args.denoise_steps,
+            "config": {"workload": "%s: Tango-full%s UNet (%s) %d-step DDPM CFG=%g denoise%s + mel-VAE decode + "
+                                   "HiFi-GAN, %d prompts/GPU x %d tokens" % (workload_name(args), " XL" if args.xl else "", "891M" if args.xl else "866M", args.denoise_steps,
                                                                              args.guidance, " with fp8 P.V self-attention" if args.fp8_attn else "", B, L),
                        "global_batch": Bg, "text_len": L, "denoise_steps": args.denoise_steps, "parallelism": "dp%d" % world,
                        "hipgraph": not args.no_graph, "fp8_attention": bool(args.fp8_attn), "kernel_src_sha16": kernel_source_sha16()},

@@ -21,7 +21,6 @@ struct Tuning {
   bool no_stream;           // TANGO_NO_STREAM=1        A/B: lin_stream_kernel out (plain linears only; folded-LN shapes need it)
   bool no_small_tile;       // TANGO_NO_SMALL_TILE=1    A/B: 64 x 64 tiles for small-M linears out (back to split-K + reduce / the streaming kernel) (round 3)
   bool no_xattn_fused;      // TANGO_NO_XATTN_FUSED=1   A/B: fused cross-attention block kernel out (round 3)
-  bool no_gn_fused_stats;   // TANGO_NO_GN_EPI_STATS=1  A/B: GroupNorm statistics from the producer's epilogue out (round 3)
 };
 
 inline const Tuning& tuning() {
@@ -36,7 +35,6 @@ inline const Tuning& tuning() {
     x.no_stream = on("TANGO_NO_STREAM");
     x.no_small_tile = on("TANGO_NO_SMALL_TILE");
     x.no_xattn_fused = on("TANGO_NO_XATTN_FUSED");
-    x.no_gn_fused_stats = on("TANGO_NO_GN_EPI_STATS");
     return x;
   }();
   return t;
