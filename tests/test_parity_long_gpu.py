@@ -69,6 +69,7 @@ def test_100_step_ladder_against_the_oracle():
     shapes = W.vae_decoder_param_shapes(O.VAE_CONFIG)
     shapes.update(W.hifigan_param_shapes(O.HIFIGAN_CONFIG))
     vsd = W.synth_state_dict(shapes, 1234)
+    torch.set_num_threads(min(16, os.cpu_count() or 16))         # bench.py's sweep: 16 host threads are the oracle's optimum on the GPU box
     with torch.no_grad():
         ref = O.denoise_loop(sd, O.UNET_CONFIG_LARGE, O.DDPMOracle(**O.SD21_SCHEDULER), enc, mask, lat0.clone(), N, 3.0, noises=list(noises),
                              prefix="unet.")
