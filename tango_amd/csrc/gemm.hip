@@ -353,7 +353,7 @@ int gemm_pick_splitk(int dtype, const GemmParams& p) {
   const int bn = (p.N % 160 == 0) ? 160 : (p.N >= 96 ? 128 : (p.N > 32 ? 64 : 32));
   const int bm = p.N > 32 ? 128 : 256;
   const int tiles = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-  if (tiles >= 400) return 1;
+  if (tiles >= 400) return 1;              // (round 3: no split from 256 or 128 tiles on was measured at B = 8 -- M=4096 N=1280 K=1280 x25 1.05 -> 1.44 ms)
   int s = (512 + tiles / 2) / tiles;   // aim for ~2 workgroups per CU
   if (s > nk / 3) s = nk / 3;             // keep >= 3 k-chunks per split (measured sweep, round 1 v15)
   if (s > 32) s = 32;

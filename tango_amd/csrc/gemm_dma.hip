@@ -237,7 +237,10 @@ bool gemm_dma_ok(int dtype, const GemmParams& p) {
   if (p.N % bn != 0) return false;
   if (p.K / (128 / esz) < 4) return false;
   const long tiles = (long)((p.M + 255) / 256) * (p.N / bn);
-  return tuning().force_big_kernels || tiles >= 448;
+  // linears from one tile per CU on (round 3, B = 8's level 1, profiles/r3_c13_b8_dispatch_thresholds.txt: M=16384 N=640 K=2560 x5
+  // 0.75 -> 0.37 ms, K=640 x20 0.83 (streaming kernel) -> 0.69 ms); convs / conv1d keep the round-1 threshold of 1.75 tiles per CU
+  const bool lin = p.mode == GATHER_1D && p.taps == 1;
+  return tuning().force_big_kernels || tiles >= (lin ? 256 : 448);
 }
 
 template <typename T>

@@ -233,7 +233,10 @@ bool gemm_wide_ok(int dtype, const GemmParams& p) {
   if ((p.lda * 2) % 16 != 0 || (p.Kp * 2) % 16 != 0 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return false;
   if (((uintptr_t)p.bias & 15) || ((uintptr_t)p.bias2 & 15) || (p.bias2 && p.bias2_stride % 4 != 0)) return false;
   const long tiles = (long)(p.M / 256) * (p.N / 320);
-  return tuning().force_big_kernels || tiles >= 224;
+  // 192 tiles = 3/4 of the CUs is where this kernel starts to win (round 3, profiles/r3_c13_b8_dispatch_thresholds.txt: level-2
+  // q | k | v^T at B = 8, M=4096 N=3840 K=1280 with folded LN, x5 0.68 -> 0.40 ms); at 128 tiles it is level with the streaming kernel
+  // on K = 640 and loses to the 256 x 160 kernel on K = 2560 (0.48 vs 0.37 ms)
+  return tuning().force_big_kernels || tiles >= 192;
 }
 
 template <typename T, bool GEGLU, bool RES, bool LN, bool VT = false, bool SK = false>

@@ -387,8 +387,10 @@ bool linear_stream_ok(int dtype, const GemmParams& p) {
   if (p.glu_tanh) return false;                     // the streaming epilogue implements the exact-erf gate only
   if (p.M < 4096) return false;                     // too few row groups to feed 256 CUs
   // plain linears below 16384 rows (B = 1's level 0) run faster as one launch of 64 x 64 tiles (gemm.hip small_tile_linear:
-  // x20 per step 0.514 -> 0.301 ms); at M = 16384 (B = 8's level 1) this kernel still wins (0.845 vs 1.014 ms on 128 x 160 tiles)
+  // x20 per step 0.514 -> 0.301 ms); at M = 16384 (B = 8's level 1) this kernel beats the 128 x 160 tiles (0.845 vs 1.014 ms) but
+  // not the 256 x 160 LDS-DMA kernel at one tile per CU (0.83 vs 0.69 ms, profiles/r3_c13_b8_dispatch_thresholds.txt)
   if (!p.ln_fold && p.epi == EPI_NONE && p.M < 16384 && !tuning().no_small_tile) return false;
+  if (!p.ln_fold && p.epi == EPI_NONE && p.M < 32768 && rowb == 1280 && gemm_dma_ok(dtype, p)) return false;
   int tn;
   if (rowb == 640) tn = 10;
   else if (rowb == 1280) tn = 5;
