@@ -91,3 +91,18 @@ def test_state_dict_and_errors():
     m0, l0, e0 = S.mel_spectrogram(y, other.mel_basis, other.stft_fn.forward_basis, 512, 128)
     assert m.shape == m0.shape == (1, 40, 63)
     _compare(m.cpu(), m0, "n_fft 512 / hop 128 / win 400 / 40 mels")
+
+
+def test_plan_cache_is_bounded_over_arbitrary_clip_lengths(monkeypatch):
+    """a data-preparation loop over clips of many different lengths: the front-end keeps at most MAX_PLANS workspaces alive (the engine
+    handle is rebuilt when the bound is hit) and results do not depend on where in that cycle a clip falls"""
+    monkeypatch.setattr(TacotronSTFT, "MAX_PLANS", 2)
+    stft = TacotronSTFT(**S.AUDIOLDM_STFT_CONFIG)
+    first_engine = stft.engine
+    for i, N in enumerate([4000, 4160, 5000, 4000, 7777]):
+        y = stft_wave(B=1, N=N, seed=N)
+        mel, _, _ = stft.mel_spectrogram(y.cuda())
+        m0, _, _ = S.mel_spectrogram(y, stft.mel_basis, stft.stft_fn.forward_basis)
+        _compare(mel.cpu(), m0, "clip %d (N=%d)" % (i, N))
+        assert len(stft._shapes) <= 2
+    assert stft.engine is not first_engine
