@@ -210,13 +210,30 @@ class Engine:
     def _u8(self, m):
         return m.to(self.device).to(torch.uint8).contiguous() if m is not None else None
 
+    def _check_latents(self, what, x):
+        """the UNet plans are built for ONE latent size: [*, in_channels, latent_h, latent_w]"""
+        want = (self.unet_cfg["in_channels"], self._cfg.latent_h, self._cfg.latent_w)
+        if x.dim() != 4 or tuple(x.shape[1:]) != want:
+            raise ValueError("%s must be [B, %d, %d, %d], got %s" % ((what,) + want + (tuple(x.shape),)))
+
+    def _check_cond(self, what, emb, mask, rows):
+        """a condition stream [rows, L, cross_attention_dim] and its optional mask [rows, L]: the engine reads exactly that many
+        bytes through the raw pointers, so a mis-shaped tensor must fail here, not as a device out-of-bounds read"""
+        d = self.unet_cfg["cross_attention_dim"]
+        if emb.dim() != 3 or emb.shape[0] != rows or emb.shape[2] != d or emb.shape[1] < 1:
+            raise ValueError("%s must be [%d, L, %d], got %s" % (what, rows, d, tuple(emb.shape)))
+        if mask is not None and tuple(mask.shape) != tuple(emb.shape[:2]):
+            raise ValueError("%s mask must be %s, got %s" % (what, tuple(emb.shape[:2]), tuple(mask.shape)))
+
     def unet_forward(self, sample, timestep, encoder_hidden_states, encoder_attention_mask=None, beat_features=None,
                      chord_features=None, beat_attention_mask=None, chord_attention_mask=None):
         """UNet2DConditionModel.forward; with beat / chord features, UNet2DConditionModelMusic.forward (Music configs only)"""
         x = self._f32(sample)
         enc = self._f32(encoder_hidden_states)
-        B2, L = enc.shape[0], enc.shape[1]
+        self._check_latents("sample", x)
+        B2, L = x.shape[0], enc.shape[1] if enc.dim() == 3 else 0
         mask = self._u8(encoder_attention_mask)
+        self._check_cond("encoder_hidden_states", enc, mask, B2)
         out = torch.empty_like(x)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
         music = bool(self.unet_cfg.get("music"))
@@ -226,8 +243,8 @@ class Engine:
             if music:
                 beat, chord = self._f32(beat_features), self._f32(chord_features)
                 bm, cm = self._u8(beat_attention_mask), self._u8(chord_attention_mask)
-                if beat.shape[0] != B2 or chord.shape[0] != B2:
-                    raise ValueError("beat / chord features must have the batch of encoder_hidden_states")
+                self._check_cond("beat_features", beat, bm, B2)
+                self._check_cond("chord_features", chord, cm, B2)
                 _lib.check(self.lib.tango_engine_unet_forward_music(
                     self._h, p(x), int(timestep), p(enc), p(mask), p(beat), p(bm), p(chord), p(cm), p(out), B2, L, beat.shape[1],
                     chord.shape[1], _stream_ptr()), "unet_forward_music")
@@ -242,14 +259,18 @@ class Engine:
         """In-place denoise of `latents` [B,8,256,16] (fp32 cuda).  `timesteps` int64 [N] and `coef`
         float32 [N,8] are host tables from tango_amd.scheduler."""
         assert latents.is_cuda and latents.dtype == torch.float32 and latents.is_contiguous()
+        self._check_latents("latents", latents)
         enc = self._f32(prompt_embeds)
         mask = prompt_mask.to(self.device).to(torch.uint8).contiguous() if prompt_mask is not None else None
+        rows = 2 * latents.shape[0] if guidance_scale > 1.0 else latents.shape[0]
+        self._check_cond("prompt_embeds", enc, mask, rows)
         ts = np.ascontiguousarray(np.asarray(timesteps, dtype=np.int64))
         cf = np.ascontiguousarray(np.asarray(coef, dtype=np.float32))
         assert cf.shape == (len(ts), 8)
         if noise is not None:
             noise = self._f32(noise)
-            assert noise.shape[0] == len(ts)
+            if tuple(noise.shape) != (len(ts),) + tuple(latents.shape):
+                raise ValueError("noise must be [num_steps, %s], got %s" % (", ".join(map(str, latents.shape)), tuple(noise.shape)))
         a = _lib.DenoiseArgs()
         a.latents = latents.data_ptr()
         a.prompt_embeds = enc.data_ptr()
@@ -275,13 +296,10 @@ class Engine:
             be, ce = self._f32(beat_embeds), self._f32(chord_embeds)
             bm, cm = self._u8(beat_mask), self._u8(chord_mask)
             keep = [be, ce, bm, cm]
-            if be.shape[0] != enc.shape[0] or ce.shape[0] != enc.shape[0]:
-                raise ValueError("beat / chord embeddings must have the batch of prompt_embeds")
+            self._check_cond("beat_embeds", be, bm, rows)
+            self._check_cond("chord_embeds", ce, cm, rows)
             a.beat_embeds, a.beat_len, a.beat_mask = be.data_ptr(), be.shape[1], bm.data_ptr() if bm is not None else None
             a.chord_embeds, a.chord_len, a.chord_mask = ce.data_ptr(), ce.shape[1], cm.data_ptr() if cm is not None else None
-        expect = 2 * a.batch if guidance_scale > 1.0 else a.batch
-        if enc.shape[0] != expect:
-            raise ValueError("prompt_embeds batch %d != %d" % (enc.shape[0], expect))
         with torch.cuda.device(self.device):
             _lib.check(self.lib.tango_engine_denoise(self._h, C.byref(a), _stream_ptr()), "denoise")
         return latents

@@ -70,6 +70,37 @@ def test_unet_forward_tiny(dtype):
     assert relerr(out2, ref2) <= UTOL[dtype]
 
 
+def test_mis_shaped_inputs_raise_instead_of_reading_out_of_bounds():
+    """the C ABI takes raw pointers and sizes the reads from its plan, so the shim must reject tensors of any other shape"""
+    cfg = O.UNET_CONFIG_TINY
+    e = unet_engine("tiny", "fp32")
+    d = cfg["cross_attention_dim"]
+    x = torch.randn(2, 8, 256, 16).cuda()
+    enc, mask = text_inputs(2, 13, d, 12)
+    enc, mask = enc.cuda(), mask.cuda()
+    for bad in (x[:, :, :128], x[:, :4], x[0]):
+        with pytest.raises(ValueError):
+            e.unet_forward(bad, 5, enc, mask)
+    with pytest.raises(ValueError):
+        e.unet_forward(x, 5, enc[..., : d - 8].contiguous(), mask)          # wrong embedding width
+    with pytest.raises(ValueError):
+        e.unet_forward(x, 5, enc[:1], mask[:1])                              # rows != batch
+    with pytest.raises(ValueError):
+        e.unet_forward(x, 5, enc, mask[:, :5])                               # mask of another length
+    sch = DDPMScheduler.from_config({k: SD21_SCHEDULER_CONFIG[k] for k in
+                                     ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "prediction_type", "clip_sample", "variance_type")})
+    sch.set_timesteps(2)
+    lat = torch.randn(1, 8, 256, 16).cuda()
+    args = (sch.timesteps.numpy(), sch.coef_table(), 3.0)
+    with pytest.raises(ValueError):
+        e.denoise(lat, enc[:1], mask[:1], *args)                             # CFG needs [uncond; cond] = 2 rows per latent
+    with pytest.raises(ValueError):
+        e.denoise(lat, enc, mask, *args, noise=torch.randn(2, 1, 8, 128, 16).cuda())
+    with pytest.raises(ValueError):
+        e.denoise(torch.randn(1, 8, 128, 16).cuda(), enc, mask, *args)
+    e.denoise(lat, enc, mask, *args, noise=torch.randn(2, 1, 8, 256, 16).cuda())   # the well-formed call still runs
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
 def test_unet_forward_large(dtype):
     """Full Tango UNet (866 M params, configs/diffusion_model_config.json), one CFG pair, L = 64."""
