@@ -323,8 +323,15 @@ class Engine:
     def encode_text(self, input_ids, attention_mask=None):
         """FLAN-T5 encoder forward: int64 ids [B, L] (+ 0/1 mask) -> fp32 last_hidden_state [B, L, d_model] on the device."""
         ids = input_ids.detach().to(device=self.device, dtype=torch.int64).contiguous()
+        if ids.dim() != 2 or ids.numel() == 0:
+            raise ValueError("encode_text: input_ids must be [B, L], got %s" % (tuple(ids.shape),))
         B, L = ids.shape
+        lo, hi = int(ids.min()), int(ids.max())           # one sync per prompt batch; nn.Embedding device-asserts on the same condition
+        if lo < 0 or hi >= self.t5_cfg["vocab_size"]:
+            raise IndexError("encode_text: token id %d outside the embedding table [0, %d)" % (lo if lo < 0 else hi, self.t5_cfg["vocab_size"]))
         m = attention_mask.detach().to(self.device).to(torch.uint8).contiguous() if attention_mask is not None else None
+        if m is not None and tuple(m.shape) != (B, L):
+            raise ValueError("encode_text: attention_mask must be %s, got %s" % ((B, L), tuple(m.shape)))
         out = torch.empty((B, L, self.t5_cfg["d_model"]), device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.tango_engine_encode_text(self._h, C.c_void_p(ids.data_ptr()), C.c_void_p(m.data_ptr()) if m is not None else None,
@@ -393,6 +400,9 @@ class Engine:
     def vocode(self, mel):
         """mel [B,1,T,num_mels] fp32 -> int16 cuda tensor [B, samples]"""
         m = self._f32(mel)
+        nm = self.hifigan_cfg.get("num_mels", 64)
+        if m.dim() != 4 or m.shape[1] != 1 or m.shape[3] != nm or m.shape[2] < 1:
+            raise ValueError("vocode: mel must be [B, 1, T, %d], got %s" % (nm, tuple(m.shape)))
         B, T = m.shape[0], m.shape[2]
         n = self.vocoder_samples(T)
         wav = torch.empty((B, n), device=self.device, dtype=torch.int16)
