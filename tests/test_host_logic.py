@@ -336,3 +336,49 @@ def test_isa_scan_finds_no_streaming_miscompare_pattern():
     assert "gemm_pers_kernel" not in names and "Lb1ELb0EEEvNS_10GemmParamsE" not in "".join(l for l in names.splitlines() if "lin_stream" in l)
     # ablation / lock-step variants of the 256 x 160 kernels are not instantiated any more
     assert not [l for l in names.splitlines() if "conv3x3_halo_kernel" in l and ("Lb1ELb0E" in l or "Lb0ELb1E" in l)]
+
+
+def test_bench_labels_and_traffic_gate(tmp_path, monkeypatch):
+    """bench.py must say what RAN: the workload label follows the flags, and `roofline.traffic` only comes from
+    a PMC record taken on the kernel sources being benchmarked"""
+    import argparse
+    import json
+
+    import bench
+
+    def ns(**kw):
+        d = dict(guidance=3.0, text_len=64, xl=False, fp8_attn=False, batch=32, denoise_steps=200, dtype="fp16")
+        d.update(kw)
+        return argparse.Namespace(**d)
+
+    assert bench.workload_name(ns()).startswith("BASELINE config 3")
+    assert bench.workload_name(ns(batch=1, denoise_steps=100)).startswith("BASELINE config 2")
+    assert "config 5" in bench.workload_name(ns(xl=True, fp8_attn=True, dtype="bf16", batch=8))
+    for other in (ns(batch=8), ns(denoise_steps=20), ns(guidance=2.0), ns(text_len=128), ns(fp8_attn=True)):
+        assert bench.workload_name(other).startswith("custom"), bench.workload_name(other)
+    # traffic: a record is used only when batch / dtype / flags AND the source hash match
+    sha = bench.kernel_source_sha16()
+    assert len(sha) == 16
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    rec = {"records": [{"batch": 32, "dtype": "fp16", "xl": False, "fp8_attn": False, "src_sha16": "0" * 16, "bytes_per_step": 1.0, "source": "stale"},
+                       {"batch": 32, "dtype": "fp16", "xl": False, "fp8_attn": False, "src_sha16": sha, "bytes_per_step": 2.0, "source": "fresh"}]}
+    (prof / "hbm_traffic.json").write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_sha16", lambda: sha)
+    assert bench.hbm_traffic(32, "fp16", False, False) == (2.0, "fresh")
+    assert bench.hbm_traffic(8, "fp16", False, False) == (None, None)
+    assert bench.hbm_traffic(32, "bf16", False, False) == (None, None)
+    assert bench.hbm_traffic(32, "fp16", False, True) == (None, None)
+    monkeypatch.setattr(bench, "kernel_source_sha16", lambda: "f" * 16)
+    assert bench.hbm_traffic(32, "fp16", False, False) == (None, None)
+
+
+def test_committed_traffic_record_matches_the_committed_kernel_sources():
+    """the PMC record bench.py reports must have been taken on the sources in the tree (it is re-measured whenever csrc/ changes)"""
+    import bench
+
+    t, src = bench.hbm_traffic(32, "fp16", False, False)
+    if t is None:          # mid-round state after a kernel edit: bench.py reports traffic = null until tools/final_profiles.sh is re-run
+        pytest.skip("profiles/hbm_traffic.json has no record for kernel sources %s (re-measure before the round ends)" % bench.kernel_source_sha16())
+    assert os.path.exists(os.path.join(ROOT, src)) and 5e10 < t < 3e11
