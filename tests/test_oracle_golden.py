@@ -301,3 +301,30 @@ def test_int16_cast_semantics():
     """hifigan/utilities.py:81: truncation toward zero; +1.0 * 32768 wraps to -32768 (x86 numpy)"""
     w = torch.tensor([[0.99999, -0.99999, 0.5 / 32768, -0.5 / 32768, 1.5 / 32768, -1.5 / 32768, -1.0]])
     assert O.wav_to_int16(w).tolist() == [[32767, -32767, 0, 0, 1, -1, -32768]]
+
+
+def test_unconditional_rows_cross_attention_is_query_independent():
+    """Structure of the CFG batch: the unconditional half is T5("") padded to the prompt length, i.e. ONE
+    valid key (models.py:282-289).  With the reference's additive -10000 mask bias the other keys' softmax weights underflow to exactly
+    0 in fp32, so attn2's output for those rows is exactly to_out(v_0) -- independent of the query.  This pins the premise of the
+    planned single-key fast path on the oracle (bit-exact, not approximately)."""
+    torch.manual_seed(5)
+    C, heads, L, d_text, S = 64, 4, 9, 32, 50
+    sd = {"a.to_q.weight": torch.randn(C, C) * 0.3, "a.to_k.weight": torch.randn(C, d_text) * 0.3, "a.to_v.weight": torch.randn(C, d_text) * 0.3,
+          "a.to_out.0.weight": torch.randn(C, C) * 0.3, "a.to_out.0.bias": torch.randn(C)}
+    x = torch.randn(2, S, C) * 3.0
+    ctx = torch.randn(2, L, d_text)
+    mask = torch.ones(2, L, dtype=torch.bool)
+    mask[0, 1:] = False                                   # row 0 = unconditional: token 0 only; row 1 = a full prompt
+    out = O.attention(sd, "a", x, heads, ctx, O._mask_bias(mask, torch.float32))
+    v0 = torch.nn.functional.linear(ctx[0, :1], sd["a.to_v.weight"])                      # [1, C]: all heads' slices of v_0
+    const = torch.nn.functional.linear(v0, sd["a.to_out.0.weight"], sd["a.to_out.0.bias"])
+    # the softmax weights themselves: exactly one-hot on key 0 for the unconditional sample
+    d = C // heads
+    q = torch.nn.functional.linear(x, sd["a.to_q.weight"]).view(2, S, heads, d).transpose(1, 2)
+    k = torch.nn.functional.linear(ctx, sd["a.to_k.weight"]).view(2, L, heads, d).transpose(1, 2)
+    probs = (torch.matmul(q, k.transpose(-1, -2)) * d ** -0.5 + O._mask_bias(mask, torch.float32)[:, None]).softmax(-1)
+    assert torch.equal(probs[0, :, :, 0], torch.ones(heads, S)) and torch.count_nonzero(probs[0, :, :, 1:]) == 0
+    assert torch.equal(out[0], out[0, :1].expand(S, C))   # every query row of the unconditional sample gets the same vector, bit for bit
+    assert torch.allclose(out[0, 0], const[0], rtol=1e-5, atol=1e-5)      # ... and it is to_out(v_0) (a [1, C] GEMM rounds differently in the last bit)
+    assert not torch.allclose(out[1, 0], out[1, 1])       # the conditional sample's rows do depend on their queries
