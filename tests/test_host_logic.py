@@ -329,13 +329,38 @@ def test_isa_scan_finds_no_streaming_miscompare_pattern():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_scan.py"), "--lib", lib, "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     tot = [l for l in r.stdout.splitlines() if l.startswith("# totals")][0]
-    assert "xor_fed 0," in tot and "both 0" in tot, tot
+    assert "xor_fed 0," in tot and "both 0" in tot and "mfma_raw 0" in tot, tot
     ln = [l for l in r.stdout.splitlines() if "[LN]" in l]
     assert len(ln) >= 10, "folded-LayerNorm kernels must be recognised by name (%d found)" % len(ln)
     names = r.stdout
     assert "gemm_pers_kernel" not in names and "Lb1ELb0EEEvNS_10GemmParamsE" not in "".join(l for l in names.splitlines() if "lin_stream" in l)
     # ablation / lock-step variants of the 256 x 160 kernels are not instantiated any more
     assert not [l for l in names.splitlines() if "conv3x3_halo_kernel" in l and ("Lb1ELb0E" in l or "Lb0ELb1E" in l)]
+
+
+def test_isa_scan_mfma_read_hazard_detector():
+    """round 3: hipcc does not pad MFMA -> VALU read hazards for inline-asm operands (the first fused cross-attention kernel read fresh
+    accumulators one slot after the MFMA and was not repeatable).  The scanner counts wait states between a v_mfma and the first
+    non-MFMA reader of its destination; the shipped form (s_nop padding) must pass, the failing form must be flagged."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import isa_scan as I
+
+    def prog(*lines):
+        return [I.parse_inst("\t" + l) for l in lines]
+
+    mfma = "v_mfma_f32_16x16x32_f16 v[122:125], v[186:189], v[42:45], v[122:125]"
+    bad = prog(mfma, "v_add_u32_e32 v1, v2, v3", "v_fma_f32 v218, -v140, v218, v122")
+    assert I.scan_mfma_raw(bad)[0] == 1
+    padded = prog(mfma, "s_nop 15", "s_nop 7", "v_fma_f32 v218, -v140, v218, v122")
+    assert I.scan_mfma_raw(padded)[0] == 0
+    chained = prog(mfma, "v_mfma_f32_16x16x32_f16 v[122:125], v[190:193], v[46:49], v[122:125]", "s_nop 6", "v_cvt_pk_f16_f32 v5, v122, v123")
+    assert I.scan_mfma_raw(chained)[0] == 0           # the accumulate chain is the matrix pipe's own dependency; the last MFMA is 7 away
+    f32 = prog("v_mfma_f32_16x16x4_f32 v[116:119], v154, v102, v[116:119]", "s_nop 6", "v_mul_f32_e32 v9, v116, v8")
+    assert I.scan_mfma_raw(f32)[0] == 1               # the 8-pass fp32 MFMA needs more than the 4-pass 16-bit one
+    stored = prog(mfma, "global_store_dwordx4 v[10:11], v[122:125], off")
+    assert I.scan_mfma_raw(stored)[0] == 1            # memory instructions read registers too
 
 
 def test_bench_labels_and_traffic_gate(tmp_path, monkeypatch):

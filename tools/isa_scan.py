@@ -20,7 +20,14 @@ tool is the tripwire for a compiler upgrade or a new epilogue re-creating the fo
   war_pk     a VALU write, <= 2 instructions after a v_pk_* instruction, to a register that v_pk_* reads as a source
              and does not itself write                                                  (the failing register reuse)
 
-`--check` exits non-zero if any kernel has xor_fed > 0 AND war_pk > 0 at the same site (the exact failing shape) or if a
+  mfma_raw   (round 3) a non-MFMA instruction that READS the destination of a v_mfma fewer wait states later than the hardware
+             needs (s_nop N counts N + 1, every other instruction 1).  hipcc pads these hazards for the instructions it
+             models but NOT for inline-asm operands: the fused cross-attention kernel's asm `v_fma_f32` read fresh Q accumulators
+             three slots after the last MFMA and its output differed between repetitions until `s_nop`s were added
+             (tango_amd/csrc/xattn.hip).  Thresholds are the smallest distances hipcc itself leaves in this library:
+             7 for the 4-pass v_mfma_f32_16x16x32_{f16,bf16,fp8}, 10 for the 8-pass v_mfma_f32_16x16x4_f32.
+
+`--check` exits non-zero if any kernel has mfma_raw > 0, or xor_fed > 0 AND war_pk > 0 at the same site (the exact failing shape) or if a
 folded-LayerNorm kernel (lin_stream_kernel<.., LN = true, ..>, gemm_wide_kernel<.., LN = true, ..>, xattn / any kernel whose
 name is given with --strict) has xor_fed > 0.
 
@@ -137,6 +144,42 @@ def scan_kernel(insts):
     return xor_fed, war_pk, both, sites
 
 
+def mfma_need(mn):
+    """wait states a non-MFMA reader of this MFMA's destination must be away (empirical floor of compiler-generated code here)"""
+    if "_f32_16x16x4_f32" in mn or "32x32" in mn:
+        return 10
+    return 7
+
+
+def scan_mfma_raw(insts):
+    """(count, example sites) of non-MFMA instructions reading a v_mfma destination too early"""
+    n, hits, sites = len(insts), 0, []
+    for i, (mn, ops, text) in enumerate(insts):
+        if not mn.startswith("v_mfma"):
+            continue
+        w, _ = dst_src(mn, ops)
+        need, ws = mfma_need(mn), 0
+        for j in range(i + 1, min(n, i + 24)):
+            mn2, ops2, t2 = insts[j]
+            if ws >= need or mn2.startswith(("s_branch", "s_cbranch", "s_endpgm", "s_setpc", "s_barrier")):
+                break
+            w2, r2 = dst_src(mn2, ops2)
+            if mn2.startswith("v_mfma"):
+                if w2 & w:
+                    break                      # accumulated / overwritten in the matrix pipe: a different (interlocked) dependency
+                ws += 1
+                continue
+            named = set().union(*[regs(o) for o in ops2]) if ops2 else set()
+            if ((named - w2) | r2) & w:
+                hits += 1
+                sites.append("%s  ->  %s  (%d wait states, %d needed)" % (text, t2, ws, need))
+                break
+            if w2 & w:
+                break                          # overwritten without being read (WAW is a separate, compiler-handled class)
+            ws += (int(ops2[0], 0) + 1) if mn2 == "s_nop" and ops2 else 1
+    return hits, sites
+
+
 def disassemble(lib):
     tmp = tempfile.mkdtemp(prefix="isa_scan_")
     try:
@@ -203,17 +246,19 @@ def main():
         if not insts:
             continue
         xf, war, both, sites = scan_kernel(insts)
+        raw, raw_sites = scan_mfma_raw(insts)
         npk = sum(1 for i in insts if i[0] == "v_pk_fma_f32")
-        rows.append((dm[name], len(insts), npk, xf, war, both))
-        if both > 0 or (xf > 0 and is_ln_kernel(dm[name])):
-            bad.append((dm[name], xf, war, both, sites[:3]))
+        rows.append((dm[name], len(insts), npk, xf, war, both, raw))
+        if both > 0 or (xf > 0 and is_ln_kernel(dm[name])) or raw > 0:
+            bad.append((dm[name], xf, war, both, (raw_sites or sites)[:3]))
     lines = ["# tools/isa_scan.py over %s: %d kernels" % (os.path.relpath(a.lib, ROOT), len(rows)),
-             "# columns: instructions, v_pk_fma_f32, xor_fed, war_pk, both-at-one-site (the failing shape)   [LN = folded-LayerNorm epilogue]",
-             "%8s %8s %8s %8s %6s  %s" % ("insts", "pk_fma", "xor_fed", "war_pk", "both", "kernel")]
-    for d, n, npk, xf, war, both in rows:
-        lines.append("%8d %8d %8d %8d %6d  %s%s" % (n, npk, xf, war, both, "[LN] " if is_ln_kernel(d) else "", d))
-    tot = [sum(r[i] for r in rows) for i in (3, 4, 5)]
-    lines.append("# totals: xor_fed %d, war_pk %d, both %d; flagged kernels: %d" % (tot[0], tot[1], tot[2], len(bad)))
+             "# columns: instructions, v_pk_fma_f32, xor_fed, war_pk, both-at-one-site (the round-2 failing shape), mfma_raw (early read "
+             "of an MFMA result: the round-3 inline-asm hazard)   [LN = folded-LayerNorm epilogue]",
+             "%8s %8s %8s %8s %6s %8s  %s" % ("insts", "pk_fma", "xor_fed", "war_pk", "both", "mfma_raw", "kernel")]
+    for d, n, npk, xf, war, both, raw in rows:
+        lines.append("%8d %8d %8d %8d %6d %8d  %s%s" % (n, npk, xf, war, both, raw, "[LN] " if is_ln_kernel(d) else "", d))
+    tot = [sum(r[i] for r in rows) for i in (3, 4, 5, 6)]
+    lines.append("# totals: xor_fed %d, war_pk %d, both %d, mfma_raw %d; flagged kernels: %d" % (tot[0], tot[1], tot[2], tot[3], len(bad)))
     for d, xf, war, both, sites in bad:
         lines.append("# FLAGGED %s: xor_fed %d war_pk %d both %d e.g. %s" % (d, xf, war, both, sites))
     txt = "\n".join(lines)
