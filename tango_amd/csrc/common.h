@@ -252,6 +252,13 @@ bool xattn_block_ok(int dtype, int C, int heads, int HW, int L, int64_t ldx, int
 int launch_xattn_block(int dtype, const XAttnParams& p, hipStream_t s);
 int launch_xattn_permute_wq(int dtype, const void* W, const float* b, const float* wsum, void* Wp, float* bp, float* wsp, int C, hipStream_t s);
 
+// single-key cross-attention rows (round 4): cvec[b][n] = bo[n] + sum_j Wo[n][j] * V^T[b][j][key0[b]]  (fp32), b < nb;
+// then y[r][c] = x[r][c] + cvec[r / rows_per][c] for the rows of those samples (= attn2(norm2(x)) + x when one key is unmasked)
+int launch_xattn_const(int dtype, const void* vt, int64_t ldvt, int C, const int* key0, const void* wo, int64_t ldwo, const float* bo,
+                       float* cvec, int nb, hipStream_t s);
+int launch_rowbias_add(int dtype, const void* x, int64_t ldx, const float* cvec, void* y, int64_t ldy, int64_t rows, int rows_per, int C,
+                       hipStream_t s);
+
 // row softmax (in place) used by the VAE single-head 512-d attention: x[rows][cols] *= scale; softmax
 int launch_softmax_rows(int dtype, void* x, int64_t ld, int rows, int cols, float scale, hipStream_t s);
 

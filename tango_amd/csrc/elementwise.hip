@@ -504,4 +504,69 @@ int launch_t5_pos_bias(const float* table, const int* bucket, float* out, int he
   return 0;
 }
 
+// ---- single-key cross-attention rows (round 4) -----------------------------------------------------------------------------
+// A sample whose text mask keeps exactly ONE key (the unconditional rows of a CFG batch: T5("") padded, models.py:282-289) has
+// softmax weights exactly (1, 0, ..., 0) under the reference's additive -10000 bias (exp underflows to 0 in fp32), so
+//   attn2(norm2(x), text) + x  ==  to_out(v_key) + b_out + x
+// for every query row: cvec is computed once per call (step-invariant), the per-step work is a broadcast add.
+template <typename T>
+__global__ __launch_bounds__(256) void xattn_const_kernel(const T* __restrict__ vt, int64_t ldvt, int C, const int* __restrict__ key0,
+                                                          const T* __restrict__ wo, int64_t ldwo, const float* __restrict__ bo,
+                                                          float* __restrict__ cvec) {
+  const int b = blockIdx.x, n = blockIdx.y * 256 + threadIdx.x;
+  if (n >= C) return;
+  const T* v = vt + (int64_t)b * C * ldvt + key0[b];          // V^T [b][j][key]: stride ldvt over j
+  const T* w = wo + (int64_t)n * ldwo;
+  float acc = 0.f;
+  for (int j = 0; j < C; ++j) acc = __builtin_fmaf(to_f(w[j]), to_f(v[(int64_t)j * ldvt]), acc);
+  cvec[(int64_t)b * C + n] = acc + (bo ? bo[n] : 0.f);
+}
+int launch_xattn_const(int dtype, const void* vt, int64_t ldvt, int C, const int* key0, const void* wo, int64_t ldwo, const float* bo,
+                       float* cvec, int nb, hipStream_t s) {
+  if (nb <= 0) return 0;
+  const dim3 grid((unsigned)nb, (unsigned)((C + 255) / 256));
+  switch (dtype) {
+    case DT_F32: hipLaunchKernelGGL((xattn_const_kernel<float>), grid, dim3(256), 0, s, (const float*)vt, ldvt, C, key0, (const float*)wo, ldwo, bo, cvec); break;
+    case DT_F16: hipLaunchKernelGGL((xattn_const_kernel<f16>), grid, dim3(256), 0, s, (const f16*)vt, ldvt, C, key0, (const f16*)wo, ldwo, bo, cvec); break;
+    case DT_BF16: hipLaunchKernelGGL((xattn_const_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)vt, ldvt, C, key0, (const bf16*)wo, ldwo, bo, cvec); break;
+    default: TANGO_FAIL("xattn_const: bad dtype");
+  }
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rowbias_add_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ cvec, T* __restrict__ y,
+                                                          int64_t ldy, int64_t rows, int rows_per, int C) {
+  constexpr int V = 16 / (int)sizeof(T);                       // elements per 16-byte piece
+  const int pieces = C / V;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * pieces) return;
+  const int64_t r = idx / pieces;
+  const int c0 = (int)(idx - r * pieces) * V;
+  const float* cv = cvec + (r / rows_per) * C + c0;
+  T in[V], out[V];
+  __builtin_memcpy(in, x + r * ldx + c0, 16);
+#pragma unroll
+  for (int u = 0; u < V; ++u) out[u] = from_f<T>(to_f(in[u]) + cv[u]);
+  __builtin_memcpy(y + r * ldy + c0, out, 16);
+}
+int launch_rowbias_add(int dtype, const void* x, int64_t ldx, const float* cvec, void* y, int64_t ldy, int64_t rows, int rows_per, int C,
+                       hipStream_t s) {
+  if (rows <= 0) return 0;
+  const int esz = dtype == DT_F32 ? 4 : 2, V = 16 / esz;
+  if (C % V != 0 || (ldx * esz) % 16 != 0 || (ldy * esz) % 16 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15))
+    TANGO_FAIL("rowbias_add: 16-byte alignment");
+  const int64_t n = rows * (C / V);
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  switch (dtype) {
+    case DT_F32: hipLaunchKernelGGL((rowbias_add_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)x, ldx, cvec, (float*)y, ldy, rows, rows_per, C); break;
+    case DT_F16: hipLaunchKernelGGL((rowbias_add_kernel<f16>), dim3(grid), dim3(256), 0, s, (const f16*)x, ldx, cvec, (f16*)y, ldy, rows, rows_per, C); break;
+    case DT_BF16: hipLaunchKernelGGL((rowbias_add_kernel<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)x, ldx, cvec, (bf16*)y, ldy, rows, rows_per, C); break;
+    default: TANGO_FAIL("rowbias_add: bad dtype");
+  }
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace tango

@@ -123,6 +123,10 @@ struct UNetPlan {
   float* bias = nullptr;    // f32 [B2*L]             (== biases[0])
   void* encs[3] = {nullptr, nullptr, nullptr};
   float* biases[3] = {nullptr, nullptr, nullptr};
+  // single-key prefix (round 4): the first n_short samples attend to exactly ONE text key (the unconditional rows of a CFG batch are
+  // T5("") = one valid token), so their text cross-attention output is the constant to_out(v_key) + b, independent of the query
+  int n_short = 0;
+  int* key0 = nullptr;      // i32 [B2]: index of that key per sample (entries >= n_short unused)
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
 };
@@ -270,7 +274,7 @@ class Engine {
   float* d_temb = nullptr;       // [max_steps][temb]  silu(emb)
   std::vector<int64_t> temb_ts;  // cache key
   int max_steps = 1000;
-  std::map<std::array<int, 4>, std::unique_ptr<UNetPlan>> unet_plans;   // key: (B2, L_text, L_beat, L_chord)
+  std::map<std::array<int, 5>, std::unique_ptr<UNetPlan>> unet_plans;   // key: (B2, L_text, L_beat, L_chord, n_short)
   std::map<int, std::unique_ptr<VaePlan>> vae_plans;
   std::map<int, std::unique_ptr<VaePlan>> vae_enc_plans;
   std::map<std::pair<int, int>, std::unique_ptr<VaePlan>> voc_plans;
@@ -279,7 +283,8 @@ class Engine {
   int last_steps = 0;
 
   int ensure_temb(const int64_t* ts_host, int n, hipStream_t s);
-  int get_unet_plan(int B2, int L, int Lbeat, int Lchord, UNetPlan** out);
+  int get_unet_plan(int B2, int L, int Lbeat, int Lchord, int n_short, UNetPlan** out);
+  int single_key_prefix(const uint8_t* mask_dev, int B2, int L, std::vector<int>& key0, hipStream_t s);
   int build_unet(UNetPlan& P, Arena& A, bool record);
   int get_vae_plan(int B, VaePlan** out);
   int build_vae(VaePlan& P, Arena& A, bool record);
@@ -287,7 +292,7 @@ class Engine {
   int build_vae_enc(VaePlan& P, Arena& A, bool record);
   int get_voc_plan(int B, int frames, VaePlan** out);
   int build_voc(VaePlan& P, Arena& A, bool record, int frames);
-  int bind_text(UNetPlan& P, const Cond (&c)[3], hipStream_t s);
+  int bind_text(UNetPlan& P, const Cond (&c)[3], const std::vector<int>& key0, hipStream_t s);
 };
 
 }  // namespace tango

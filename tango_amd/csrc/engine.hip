@@ -6,6 +6,7 @@
 // transformer_2d.py:255-300) and skip-connection concats (unet_2d_blocks.py:2235) are free: producers
 // write straight into column slices of the pre-allocated concat buffer.
 #include "engine.h"
+#include "tuning.h"
 
 #include <algorithm>
 #include <cmath>
@@ -246,7 +247,7 @@ struct Builder {
 
   // Transformer2DModel (transformer_2d.py:214-321) + BasicTransformerBlock (attention.py:276-335)
   void transformer(const XfW& w, const TView& x, int B, int H, int W, int groups, const TView& kv, const void* kvt,
-                   const float* bias, int L, const TView& out) {
+                   const float* bias, int L, const TView& out, int nshort = 0, const float* cvec = nullptr) {
     const int C = w.C, HW = H * W;
     const int64_t rows = (int64_t)B * HW;
     const size_t m = A.mark();
@@ -267,22 +268,39 @@ struct Builder {
     { GOpt o; o.residual = &h; linear(a, rows, w.o1, h1, o); }
     TView h2 = h;                       // h is dead after h1 was produced
     const int Lp8 = (L + 7) / 8 * 8;
-    if (w.q2p && xattn_block_ok(dt, C, w.heads, HW, L, h1.ld, h2.ld, kv.ld, Lp8)) {
-      // norm2 -> attn2 (to_q, softmax(Q K^T) V over the 64 text tokens, to_out) -> + residual in ONE launch (xattn.hip)
-      XAttnParams xp;
-      xp.x = h1.p; xp.ldx = h1.ld; xp.wq = w.q2p; xp.bq = w.bq2p; xp.wsum = w.wsum2p;
-      xp.k = kv.p; xp.ldk = kv.ld; xp.vt = kvt; xp.ldvt = Lp8; xp.bias = bias;
-      xp.wo = w.o2.W; xp.ldwo = w.o2.Kp; xp.bo = w.o2.b; xp.out = h2.p; xp.ldo = h2.ld;
-      xp.M = (int)rows; xp.HW = HW; xp.L = L; xp.eps = w.ln2.eps; xp.scale = 0.125f;
-      const int d = dt;
-      push([xp, d](hipStream_t s) { return launch_xattn_block(d, xp, s); },
-           "xattn_block M=" + std::to_string(rows) + " C=" + std::to_string(C) + " L=" + std::to_string(L),
-           4.0 * rows * (double)C * C + 4.0 * rows * (double)L * C);
-    } else {
-      TView q = slice(qkv, 0, C, esz);   // reuse the qkv buffer for the cross-attention query
-      { GOpt o = nb; o.ln = &w.ln2; linear(h1, rows, w.q2, q, o); }
-      attention(q, kv, kvt, Lp8, a, bias, B, w.heads, HW, L);
-      { GOpt o; o.residual = &h1; linear(a, rows, w.o2, h2, o); }
+    // Single-key prefix (round 4): the first `nshort` samples keep exactly one text key, so attn2(norm2(x)) + x is x plus a per-sample
+    // constant (elementwise.hip: xattn_const / rowbias_add); the cross-attention proper runs on the remaining samples only.
+    const int ns = cvec ? nshort : 0;
+    const int64_t rs = (int64_t)ns * HW, rc = rows - rs;
+    auto rows_from = [&](const TView& v, int64_t r0) { TView t = v; t.p = (char*)v.p + (size_t)r0 * v.ld * esz; return t; };
+    if (ns > 0) {
+      const int d = dt, hw = HW, c = C;
+      const void* xs = h1.p; void* ys = h2.p; const int64_t lx = h1.ld, ly = h2.ld;
+      push([=](hipStream_t s) { return launch_rowbias_add(d, xs, lx, cvec, ys, ly, rs, hw, c, s); },
+           "xattn_single_key rows=" + std::to_string(rs) + " C=" + std::to_string(C));
+    }
+    if (rc > 0) {
+      const TView h1c = rows_from(h1, rs), h2c = rows_from(h2, rs), kvc = rows_from(kv, (int64_t)ns * L);
+      const void* kvtc = (const char*)kvt + (size_t)ns * C * Lp8 * esz;
+      const float* biasc = bias ? bias + (int64_t)ns * L : nullptr;
+      const int Bc = B - ns;
+      if (w.q2p && xattn_block_ok(dt, C, w.heads, HW, L, h1c.ld, h2c.ld, kvc.ld, Lp8)) {
+        // norm2 -> attn2 (to_q, softmax(Q K^T) V over the 64 text tokens, to_out) -> + residual in ONE launch (xattn.hip)
+        XAttnParams xp;
+        xp.x = h1c.p; xp.ldx = h1c.ld; xp.wq = w.q2p; xp.bq = w.bq2p; xp.wsum = w.wsum2p;
+        xp.k = kvc.p; xp.ldk = kvc.ld; xp.vt = kvtc; xp.ldvt = Lp8; xp.bias = biasc;
+        xp.wo = w.o2.W; xp.ldwo = w.o2.Kp; xp.bo = w.o2.b; xp.out = h2c.p; xp.ldo = h2c.ld;
+        xp.M = (int)rc; xp.HW = HW; xp.L = L; xp.eps = w.ln2.eps; xp.scale = 0.125f;
+        const int d = dt;
+        push([xp, d](hipStream_t s) { return launch_xattn_block(d, xp, s); },
+             "xattn_block M=" + std::to_string(rc) + " C=" + std::to_string(C) + " L=" + std::to_string(L),
+             4.0 * rc * (double)C * C + 4.0 * rc * (double)L * C);
+      } else {
+        TView q = slice(qkv, 0, C, esz);   // reuse the qkv buffer for the cross-attention query
+        { GOpt o = nb; o.ln = &w.ln2; linear(h1c, rc, w.q2, q, o); }
+        attention(q, kvc, kvtc, Lp8, a, biasc, Bc, w.heads, HW, L);
+        { GOpt o; o.residual = &h1c; linear(a, rc, w.o2, h2c, o); }
+      }
     }
     TView gg = alloc(rows, 4 * C);
     { GOpt o; o.epi = EPI_GEGLU; o.ln = &w.ln3; linear(h2, rows, w.ff1, gg, o); }
@@ -871,6 +889,20 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
       pb.linear(encv[all_xf[i]->cond], (int64_t)B2 * Li, all_xf[i]->kv2, kvs[i], o);
     }
   }
+  // single-key prefix: per text site the constant to_out(v_key) + b of the first n_short samples, computed by P.pre once per call
+  std::vector<float*> cvecs(all_xf.size(), nullptr);
+  P.key0 = (int*)A.alloc((size_t)B2 * 4);
+  if (P.n_short > 0) {
+    Builder pb{*this, A, &P.pre, record, dt, esz};
+    for (size_t i = 0; i < all_xf.size(); ++i) {
+      if (all_xf[i]->cond != 0) continue;
+      const int C = all_xf[i]->C, Lpi = (P.Lc[0] + 7) / 8 * 8, d = dt, nsh = P.n_short;
+      cvecs[i] = (float*)A.alloc((size_t)nsh * C * 4);
+      const void* vt = kvts[i]; const int* k0 = P.key0; const void* wo = all_xf[i]->o2.W; const int64_t ldwo = all_xf[i]->o2.Kp;
+      const float* bo = all_xf[i]->o2.b; float* cv = cvecs[i];
+      pb.push([=](hipStream_t s) { return launch_xattn_const(d, vt, Lpi, C, k0, wo, ldwo, bo, cv, nsh, s); }, "xattn_const");
+    }
+  }
   auto kv_idx = [&](const XfW* w) -> size_t {
     for (size_t i = 0; i < all_xf.size(); ++i) if (all_xf[i] == w) return i;
     return 0;
@@ -899,7 +931,7 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
   auto xf_site = [&](const XfW& w1, const XfW* w2, const XfW* w3, const TView& x, int lvl, const TView& out) {
     auto one = [&](const XfW& w, const TView& in, const TView& o) {
       const size_t k = kv_idx(&w);
-      b.transformer(w, in, B2, HH(lvl), WW(lvl), G, kvs[k], kvts[k], P.biases[w.cond], P.Lc[w.cond], o);
+      b.transformer(w, in, B2, HH(lvl), WW(lvl), G, kvs[k], kvts[k], P.biases[w.cond], P.Lc[w.cond], o, w.cond == 0 ? P.n_short : 0, cvecs[k]);
     };
     if (!w2) { one(w1, x, out); return; }
     const size_t m = A.mark();
@@ -991,15 +1023,16 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
   return 0;
 }
 
-int Engine::get_unet_plan(int B2, int L, int Lbeat, int Lchord, UNetPlan** out) {
+int Engine::get_unet_plan(int B2, int L, int Lbeat, int Lchord, int n_short, UNetPlan** out) {
   if (cfg.unet_music && (Lbeat <= 0 || Lchord <= 0)) TANGO_FAIL("engine: the Music UNet needs beat and chord conditions (beat_len, chord_len > 0)");
   if (!cfg.unet_music) { Lbeat = 0; Lchord = 0; }
-  const std::array<int, 4> key = {B2, L, Lbeat, Lchord};
+  if (n_short < 0 || n_short > B2) TANGO_FAIL("engine: bad single-key prefix");
+  const std::array<int, 5> key = {B2, L, Lbeat, Lchord, n_short};
   auto it = unet_plans.find(key);
   if (it != unet_plans.end()) { *out = it->second.get(); return 0; }
   if (!finalized) TANGO_FAIL("engine: weights not finalized");
   std::unique_ptr<UNetPlan> P(new UNetPlan());
-  P->B2 = B2; P->L = L;
+  P->B2 = B2; P->L = L; P->n_short = n_short;
   P->Lc[0] = L; P->Lc[1] = Lbeat; P->Lc[2] = Lchord;
   Arena m;
   TANGO_TRY(build_unet(*P, m, false));
@@ -1013,8 +1046,13 @@ int Engine::get_unet_plan(int B2, int L, int Lbeat, int Lchord, UNetPlan** out) 
   return 0;
 }
 
-int Engine::bind_text(UNetPlan& P, const Cond (&c)[3], hipStream_t s) {
+int Engine::bind_text(UNetPlan& P, const Cond (&c)[3], const std::vector<int>& key0, hipStream_t s) {
   const int ncond = cfg.unet_music ? 3 : 1;
+  if (P.n_short > 0) {
+    if ((int)key0.size() < P.n_short) TANGO_FAIL("engine: single-key prefix without key indices");
+    TANGO_HIP(hipMemcpyAsync(P.key0, key0.data(), (size_t)P.n_short * 4, hipMemcpyHostToDevice, s));
+    TANGO_HIP(hipStreamSynchronize(s));   // key0 is transient host memory
+  }
   for (int i = 0; i < ncond; ++i) {
     if (!c[i].emb) TANGO_FAIL("engine: missing condition embeddings");
     const int n = P.B2 * P.Lc[i];
@@ -1025,12 +1063,35 @@ int Engine::bind_text(UNetPlan& P, const Cond (&c)[3], hipStream_t s) {
   return P.pre.run(s);
 }
 
+// How many leading samples keep exactly ONE text key (and which): the unconditional half of a CFG batch is T5("") = one valid token
+// (models.py:282-289).  One small device -> host copy per call.  Only the two shapes a CFG caller produces get their own plan --
+// the whole batch, or exactly its first half -- so that odd masks cannot multiply the (large) plans.
+int Engine::single_key_prefix(const uint8_t* mask_dev, int B2, int L, std::vector<int>& key0, hipStream_t s) {
+  key0.clear();
+  if (!mask_dev || tuning().no_single_key || B2 <= 0 || L <= 0) return 0;
+  std::vector<uint8_t> m((size_t)B2 * L);
+  if (hipMemcpyAsync(m.data(), mask_dev, m.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return 0;
+  if (hipStreamSynchronize(s) != hipSuccess) return 0;
+  for (int b = 0; b < B2; ++b) {
+    int cnt = 0, idx = 0;
+    for (int j = 0; j < L; ++j) if (m[(size_t)b * L + j]) { ++cnt; idx = j; }
+    if (cnt != 1) break;
+    key0.push_back(idx);
+  }
+  const int n = (int)key0.size();
+  if (n >= B2) return B2;
+  if (B2 % 2 == 0 && n >= B2 / 2) return B2 / 2;
+  return 0;
+}
+
 int Engine::unet_forward(const float* sample, int64_t t, const Cond (&c)[3], float* out, int B2, hipStream_t s) {
   UNetPlan* P;
-  TANGO_TRY(get_unet_plan(B2, c[0].len, c[1].len, c[2].len, &P));
+  std::vector<int> key0;
+  const int ns = single_key_prefix(c[0].mask, B2, c[0].len, key0, s);
+  TANGO_TRY(get_unet_plan(B2, c[0].len, c[1].len, c[2].len, ns, &P));
   TANGO_TRY(ensure_temb(&t, 1, s));
   TANGO_HIP(hipMemsetAsync(d_step, 0, 4, s));
-  TANGO_TRY(bind_text(*P, c, s));
+  TANGO_TRY(bind_text(*P, c, key0, s));
   const int HW = cfg.latent_h * cfg.latent_w;
   TANGO_TRY(launch_fill_zero(P->xin, (size_t)B2 * HW * 8 * esz, s));
   TANGO_TRY(launch_nchw_to_nhwc(dt, sample, P->xin, 8, B2, cfg.unet_in_channels, HW, 1, 1.0f, s));
@@ -1044,7 +1105,9 @@ int Engine::denoise(const tango_denoise_args_t& a, hipStream_t s) {
   const bool cfg_on = a.guidance_scale > 1.0f;
   const int B = a.batch, B2 = cfg_on ? 2 * B : B;
   UNetPlan* P;
-  TANGO_TRY(get_unet_plan(B2, a.text_len, a.beat_len, a.chord_len, &P));
+  std::vector<int> key0;
+  const int ns = single_key_prefix(a.prompt_mask, B2, a.text_len, key0, s);
+  TANGO_TRY(get_unet_plan(B2, a.text_len, a.beat_len, a.chord_len, ns, &P));
   TANGO_TRY(ensure_temb(a.timesteps, a.num_steps, s));
   const int HW = cfg.latent_h * cfg.latent_w;
   const int C = cfg.unet_in_channels;
@@ -1065,7 +1128,7 @@ int Engine::denoise(const tango_denoise_args_t& a, hipStream_t s) {
     c[0].emb = a.prompt_embeds; c[0].mask = a.prompt_mask; c[0].len = a.text_len;
     c[1].emb = a.beat_embeds; c[1].mask = a.beat_mask; c[1].len = a.beat_len;
     c[2].emb = a.chord_embeds; c[2].mask = a.chord_mask; c[2].len = a.chord_len;
-    TANGO_TRY(bind_text(*P, c, s));
+    TANGO_TRY(bind_text(*P, c, key0, s));
   }
   TANGO_TRY(launch_fill_zero(P->xin, (size_t)B2 * HW * 8 * esz, s));
   TANGO_TRY(launch_nchw_to_nhwc(dt, a.latents, P->xin, 8, B, C, HW, cfg_on ? 2 : 1, 1.0f, s));
@@ -1122,7 +1185,9 @@ int Program::run_profiled(hipStream_t s, std::string& report) const {
 
 int Engine::profile_unet(int B2, int L, std::string& report, hipStream_t s) {
   UNetPlan* P;
-  TANGO_TRY(get_unet_plan(B2, L, cfg.unet_music ? 50 : 0, cfg.unet_music ? 20 : 0, &P));   // mustango/models.py:336,340: beat_len 50, chord_len 20
+  // the product's CFG structure: the first half of the batch is the unconditional (single-key) half
+  const int ns = (!tuning().no_single_key && B2 % 2 == 0) ? B2 / 2 : 0;
+  TANGO_TRY(get_unet_plan(B2, L, cfg.unet_music ? 50 : 0, cfg.unet_music ? 20 : 0, ns, &P));   // mustango/models.py:336,340: beat_len 50, chord_len 20
   int64_t t = 500;
   TANGO_TRY(ensure_temb(&t, 1, s));
   TANGO_HIP(hipMemsetAsync(d_step, 0, 4, s));

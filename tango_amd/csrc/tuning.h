@@ -21,6 +21,7 @@ struct Tuning {
   bool no_stream;           // TANGO_NO_STREAM=1        A/B: lin_stream_kernel out (plain linears only; folded-LN shapes need it)
   bool no_small_tile;       // TANGO_NO_SMALL_TILE=1    A/B: 64 x 64 tiles for small-M linears out (back to split-K + reduce / the streaming kernel) (round 3)
   bool no_xattn_fused;      // TANGO_NO_XATTN_FUSED=1   A/B: fused cross-attention block kernel out (round 3)
+  bool no_single_key;       // TANGO_NO_SINGLE_KEY=1    A/B: single-key (unconditional-row) cross-attention shortcut out (round 4)
 };
 
 inline const Tuning& tuning() {
@@ -35,6 +36,7 @@ inline const Tuning& tuning() {
     x.no_stream = on("TANGO_NO_STREAM");
     x.no_small_tile = on("TANGO_NO_SMALL_TILE");
     x.no_xattn_fused = on("TANGO_NO_XATTN_FUSED");
+    x.no_single_key = on("TANGO_NO_SINGLE_KEY");
     return x;
   }();
   return t;
