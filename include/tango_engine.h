@@ -199,6 +199,9 @@ int tango_engine_last_denoise_ms(tango_engine_t* h, float* total_ms, float* per_
 /* diagnostic: eager run of one UNet step with HIP events around every kernel group; writes
  * "label<TAB>ms<TAB>GFLOP" lines into `report` (truncated to report_cap). */
 int tango_engine_profile_unet(tango_engine_t* h, int batch2, int text_len, char* report, int report_cap, void* stream);
+/* measurement tools only: re-read the TANGO_* dispatch switches (csrc/tuning.h) from the environment, so that one process can
+ * time several arms of an A/B back to back (tools/profile_unet_ops.py --ab).  No reference counterpart. */
+void tango_tuning_reload(void);
 
 /* ---- per-operator entry points (parity tests; fp32 reference-layout tensors on device) ---- */
 int tango_op_conv2d(int dtype, const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,

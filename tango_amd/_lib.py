@@ -98,7 +98,7 @@ class DenoiseArgs(C.Structure):
 
 #: every symbol include/tango_engine.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "tango_last_error", "tango_version", "tango_engine_create", "tango_engine_destroy",
+    "tango_last_error", "tango_version", "tango_tuning_reload", "tango_engine_create", "tango_engine_destroy",
     "tango_engine_num_weights", "tango_engine_weight_name", "tango_engine_set_weight",
     "tango_engine_finalize_weights", "tango_engine_denoise", "tango_engine_unet_forward", "tango_engine_unet_forward_music",
     "tango_engine_vae_decode", "tango_engine_vae_encode", "tango_engine_vocode", "tango_engine_vocoder_samples", "tango_engine_encode_text",
@@ -124,6 +124,7 @@ def load():
     vp, ci, cf, i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
     lib.tango_last_error.restype = C.c_char_p
     lib.tango_version.restype = C.c_char_p
+    lib.tango_tuning_reload.restype = None
     lib.tango_engine_create.argtypes = [C.POINTER(TangoConfig), C.POINTER(vp)]
     lib.tango_engine_destroy.argtypes = [vp]
     lib.tango_engine_destroy.restype = None

@@ -49,6 +49,10 @@ void set_error(const std::string& msg);
     if (_r != 0) return _r;   \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: remembered per (function, device) under a
+// mutex, so that a second engine on another GPU of the same process opts in as well (gemm.hip)
+int ensure_dyn_lds(const void* kfn, int bytes);
+
 // ---- device helpers ----
 template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f(float v) { return (T)v; }

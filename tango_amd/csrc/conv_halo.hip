@@ -336,11 +336,7 @@ static int launch_halo_cfg(const GemmParams& p, const unsigned char* zero_page, 
   // equal on the UNet convs -- 3.81 vs 3.71 ms on the level-0 convs, profiles/r2_unet_ops_pp_vs_lockstep.txt -- and the
   // ablation hooks are a tools/ build: tools/halo_ablation.sh documents how the round-1 table was taken.)
   auto kfn = conv3x3_halo_kernel<T, BN, false, false>;
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
-    TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_lds = lds;
-  }
+  TANGO_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(kfn), lds));
   const int tiles = (p.M / 256) * (p.N / BN);
   const int staged = epilogue_can_stage<T>(p) ? 1 : 0;
   const int abl = 0, pp_mode = 0;

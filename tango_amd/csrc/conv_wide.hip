@@ -29,7 +29,16 @@ static constexpr int CW_HALO_MAX = 544;    // halo pixels per tile: 2 x 34 KiB h
                                            // (544 = four 32 x 2 images with their borders: the UNet's level 3)
 static constexpr int CW_NA = 5;            // halo DMA pieces (16 rows) per wave per channel chunk: 8 waves x 5 x 16 rows >= 544
 
-template <typename T, bool RES, bool SK>
+// SCH: where the LDS-DMAs of an item (one halo piece of the next chunk during taps 0..4, the weight rows of item i+3) are issued
+// (round 4, as in gemm_wide.hip):
+//   0  at the head of the multiply part, source offsets fetched from LDS there (rounds 2-3: two LDS round trips + the DMA issue
+//      in front of the first MFMA)
+//   1  inside the MFMA stream, one DMA every eight MFMAs; the source offsets are fetched in the read part
+//   2  halo piece + first weight group in the READ part, the other weight groups inside the MFMA stream
+//   3  everything in the read part
+// 2 and 3 overwrite the stage of item i-1 (and, at tap 0, the halo buffer of chunk cc-1) one slot earlier: every wave retires its
+// fragment reads (lgkmcnt(0)) before the barrier that ends its read part.
+template <typename T, bool RES, bool SK, int SCH>
 __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, const unsigned char* zero_page, const int SR, const int nseg,
                                                            const int abytes) {
   constexpr int BM = 256, BN = 320, CB = 64, NST = 4;
@@ -38,6 +47,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
   constexpr int WRG = BN / 16;                  // 16-row DMA groups per weight item: 20
   constexpr int WRGW = (WRG + 7) / 8;           // per wave: 3 (waves 0-3) or 2
   constexpr int TM = 4, TN = 10;
+  constexpr int NRW = SCH == 2 ? 1 : SCH == 3 ? WRGW : 0;   // weight groups of an item issued in the read part
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // [halo 0 | halo 1 | W stage 0..3]
   unsigned char* const As = dsm;
   unsigned char* const Ws = dsm + 2 * abytes;
@@ -86,46 +96,49 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
   // weight DMA sources: row group rg = wave + 8 i, row = rg*16 + lrow: 32-bit offset of group 0 from the tile's first weight
   // row, groups 1, 2 are 128 rows further each (same swizzle: (128 >> 1) & 2 == 0)
   const int wrow_d = wave * 16 + lrow;
-  aoff_lds[CW_NA * 512] = (unsigned)(((int64_t)wrow_d * p.Kp) * (int64_t)sizeof(T) + ((slot ^ ((wrow_d >> 1) & 2)) * 16));
+  const unsigned w_off0_init = (unsigned)(((int64_t)wrow_d * p.Kp) * (int64_t)sizeof(T) + ((slot ^ ((wrow_d >> 1) & 2)) * 16));
+  aoff_lds[CW_NA * 512] = w_off0_init;
   const unsigned w_step = (unsigned)(128 * p.Kp * (int64_t)sizeof(T));
   const unsigned char* const Wt = Wb + (int64_t)n0 * p.Kp * (int64_t)sizeof(T);
   const int my_w = wave < WRG - 8 * (WRGW - 1) ? WRGW : WRGW - 1;      // wave-uniform
+  const int my_rw = NRW < my_w ? NRW : my_w;                            // of them in the read part
 
+  auto issue_a_off = [&](const int t, const int cc, const int buf, const unsigned off) {
+    const unsigned char* src = off != ~0u ? Ab + (int64_t)cc * CB + off : zero_page;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * abytes + (t * 8 + wave) * 1024), 16, 0, 0);
+  };
   auto issue_a = [&](const int t, const int cc, const int buf) {
-    const int ag = t * 8 + wave;
-    if (ag < HALO_RG) {
-      const unsigned off = aoff_lds[t * 512];
-      const unsigned char* src = off != ~0u ? Ab + (int64_t)cc * CB + off : zero_page;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * abytes + ag * 1024), 16, 0, 0);
-    }
+    if (t * 8 + wave < HALO_RG) issue_a_off(t, cc, buf, aoff_lds[t * 512]);
   };
   // (the item's k offset is wave-uniform and made opaque per call: otherwise hipcc hoists the 27 (tap, group) source addresses
   //  out of the chunk loop as 64-bit VGPR pairs and spills them)
-  auto issue_w = [&](const int tap, const int cc, const int st) {
-    int koff = (tap * p.Cin + cc * BK) * (int)sizeof(T);
-    asm volatile("" : "+s"(koff));
-    const unsigned char* base = Wt + koff;
-    const unsigned w_off0 = aoff_lds[CW_NA * 512];
-#pragma unroll
-    for (int i = 0; i < WRGW; ++i) {
-      const int rg = wave + 8 * i;
-      if (rg < WRG) {
-        unsigned o = w_off0 + i * w_step;
-        asm volatile("" : "+v"(o));               // keeps the zero-extended 64-bit forms of the three offsets out of the loop-invariant set
-        __builtin_amdgcn_global_load_lds((gptr_t)(base + o), (lptr_t)(Ws + st * WST + rg * 1024), 16, 0, 0);
-      }
+  auto issue_w_one = [&](const int i, int koff, const int st, const unsigned w_off0) {
+    const int rg = wave + 8 * i;
+    if (rg < WRG) {
+      asm volatile("" : "+s"(koff));
+      const unsigned char* base = Wt + koff;
+      unsigned o = w_off0 + i * w_step;
+      asm volatile("" : "+v"(o));               // keeps the zero-extended 64-bit forms of the three offsets out of the loop-invariant set
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + o), (lptr_t)(Ws + st * WST + rg * 1024), 16, 0, 0);
     }
   };
-  // at most the youngest `items` weight items of this wave may stay in flight (halo pieces are older than the weight item
-  // issued behind them, so they are covered by the same wait)
-  auto wait_items = [&](const int items) {
-    if (items <= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-    if (my_w == WRGW) {
-      if (items == 1) wait_vmcnt_lit<WRGW>();
-      else wait_vmcnt_lit<2 * WRGW>();
-    } else {
-      if (items == 1) wait_vmcnt_lit<WRGW - 1>();
-      else wait_vmcnt_lit<2 * (WRGW - 1)>();
+  auto issue_w = [&](const int tap, const int cc, const int st) {
+    const int koff = (tap * p.Cin + cc * BK) * (int)sizeof(T);
+    const unsigned w_off0 = aoff_lds[CW_NA * 512];
+#pragma unroll
+    for (int i = 0; i < WRGW; ++i) issue_w_one(i, koff, st, w_off0);
+  };
+  auto wait_n = [&](const int n) {    // at most n of this wave's DMAs stay in flight (wave-uniform)
+    switch (n) {
+      case 0: wait_vmcnt_lit<0>(); break;
+      case 1: wait_vmcnt_lit<1>(); break;
+      case 2: wait_vmcnt_lit<2>(); break;
+      case 3: wait_vmcnt_lit<3>(); break;
+      case 4: wait_vmcnt_lit<4>(); break;
+      case 5: wait_vmcnt_lit<5>(); break;
+      case 6: wait_vmcnt_lit<6>(); break;
+      case 7: wait_vmcnt_lit<7>(); break;
+      default: wait_vmcnt_lit<8>(); break;
     }
   };
 
@@ -168,10 +181,11 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
   issue_w(0, cc0, 0);
   issue_w(1, cc0, 1);
   issue_w(2, cc0, 2);
-  wait_items(2);
+  wait_n(2 * my_w);
   pp_barrier();
   if (half) pp_barrier();                           // the stagger: half B starts one slot late
   int st = 0, item = 0;
+  int prev_h = 0;                                   // did the previous item issue a halo piece (it is younger than item i+1's weights)
   for (int cc = cc0; cc < cc1; ++cc) {
     const unsigned char* Ah = As + (cc & 1) * abytes;
     const bool more_c = cc + 1 < cc1;
@@ -179,7 +193,22 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
     for (int tap = 0; tap < 9; ++tap, ++item) {
       const unsigned char* Wst = Ws + st * WST;
       const int toff = (tap / 3) * HW2 + (tap % 3);
+      // what this item issues: halo piece `tap` of chunk cc+1, weight rows of item i+3 into the stage of item i-1
+      const bool iss_h = more_c && tap < CW_NA && tap * 8 + wave < HALO_RG;
+      const bool iss_w = item + 3 < NI;
+      const int st3 = st == 0 ? 3 : st - 1;         // (st + 3) % 4
+      int koff3;
+      {
+        int t3 = tap + 3, c3 = cc;
+        if (t3 >= 9) { t3 -= 9; c3 = cc + 1; }
+        koff3 = (t3 * p.Cin + c3 * BK) * (int)sizeof(T);
+      }
       // ---- read part ----
+      unsigned hoff = 0, w_off0 = 0;
+      if (SCH != 0) {
+        if (iss_h) hoff = aoff_lds[tap * 512];
+        w_off0 = aoff_lds[CW_NA * 512];
+      }
       u32x4 wf[TN], xf[TM];
 #pragma unroll
       for (int a = 0; a < TN; ++a) wf[a] = *(const u32x4*)(Wst + wfoff + a * 16 * CB);
@@ -190,22 +219,48 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
         const int h = h0 + hs;
         xf[b] = *(const u32x4*)(Ah + h * CB + ((kg ^ ((h >> 1) & 2)) << 4));
       }
-      // item i+1 must have landed before the barrier that precedes anybody's read of it; item i+2 may stay in flight
-      if (item + 1 < NI) wait_items(item + 2 < NI ? 1 : 0);
+      if (SCH >= 2) {
+        if (iss_h) issue_a_off(tap, cc + 1, (cc + 1) & 1, hoff);
+        if (iss_w) {
+#pragma unroll
+          for (int i = 0; i < NRW; ++i) issue_w_one(i, koff3, st3, w_off0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // see SCH above
+      }
+      // item i+1 must have landed before the barrier that precedes anybody's read of it.  Younger than its last DMA, in issue
+      // order: [halo piece of item i-1] [weights of item i+2] and, SCH >= 2, [halo piece of this item] [read-part weights of item i+3]
+      if (item + 1 < NI) {
+        int n = prev_h + (item + 2 < NI ? my_w : 0);
+        if (SCH >= 2) n += (iss_h ? 1 : 0) + (iss_w ? my_rw : 0);
+        wait_n(n);
+      }
+      prev_h = iss_h ? 1 : 0;
       pp_barrier();
       // ---- multiply part ----
-      if (more_c && tap < CW_NA) issue_a(tap, cc + 1, (cc + 1) & 1);
-      {
+      if (SCH == 0) {
+        if (more_c && tap < CW_NA) issue_a(tap, cc + 1, (cc + 1) & 1);
         const int t3 = tap + 3;
-        const int st3 = st == 0 ? 3 : st - 1;       // (st + 3) % 4: the stage of item i-1
         if (t3 < 9) issue_w(t3, cc, st3);
         else if (more_c) issue_w(t3 - 9, cc + 1, st3);
       }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int a = 0; a < TN; ++a)
+      for (int a = 0; a < TN; ++a) {
 #pragma unroll
         for (int b = 0; b < TM; ++b) Mma<T>::run(acc[a][b], wf[a], xf[b]);
+        if ((SCH == 1 || SCH == 2) && (a & 1) == 0) {
+          // after MFMAs 4, 12, 20, 28: SCH 1 [halo piece, weight groups 0, 1, 2], SCH 2 [weight groups 1, 2]
+          const int sl = a >> 1;
+          __builtin_amdgcn_sched_barrier(0);
+          if (SCH == 1) {
+            if (sl == 0) { if (iss_h) issue_a_off(tap, cc + 1, (cc + 1) & 1, hoff); }
+            else if (sl - 1 < WRGW) { if (iss_w) issue_w_one(sl - 1, koff3, st3, w_off0); }
+          } else {
+            if (NRW + sl < WRGW) { if (iss_w) issue_w_one(NRW + sl, koff3, st3, w_off0); }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       __builtin_amdgcn_s_setprio(0);
       pp_barrier();
       st = st == NST - 1 ? 0 : st + 1;
@@ -276,25 +331,31 @@ int conv_wide_pick_splitk(int dtype, const GemmParams& p) {
   return conv_wide_ok(dtype, q) ? s : 0;
 }
 
-template <typename T, bool RES, bool SK = false>
-static int launch_conv_wide_cfg(const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {
+template <typename T, bool RES, bool SK, int SCH>
+static int launch_conv_wide_sch(const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {
   WideHaloGeom g;
   if (!wide_halo_geom(p, g)) TANGO_FAIL("conv_wide: unsupported geometry");
   const int abytes = ((g.halo + 15) / 16) * 1024;
   int lds = 2 * abytes + 4 * 320 * 64 + (CW_NA + 1) * 512 * 4;
   const int epi_lds = 8 * (WIDE_STAGE_BYTES + 1280);
   if (lds < epi_lds) lds = epi_lds;
-  auto kfn = conv3x3_wide_kernel<T, RES, SK>;
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
-    TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_lds = lds;
-  }
+  auto kfn = conv3x3_wide_kernel<T, RES, SK, SCH>;
+  TANGO_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(kfn), lds));
   const int tiles = (p.M / 256) * (p.N / 320);
   hipLaunchKernelGGL(kfn, dim3((unsigned)tiles, (unsigned)(p.splitk > 1 ? p.splitk : 1)), dim3(512), lds, s, p, zero_page, g.SR, g.nseg, abytes);
   TANGO_HIP(hipGetLastError());
   if (p.splitk > 1) TANGO_TRY(launch_splitk_reduce(TypeTag<T>::dt, p, s));
   return 0;
+}
+
+template <typename T, bool RES, bool SK = false>
+static int launch_conv_wide_cfg(const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {
+  switch (tuning().wide_sched) {
+    case 0: return launch_conv_wide_sch<T, RES, SK, 0>(p, zero_page, s);
+    case 1: return launch_conv_wide_sch<T, RES, SK, 1>(p, zero_page, s);
+    case 3: return launch_conv_wide_sch<T, RES, SK, 3>(p, zero_page, s);
+    default: return launch_conv_wide_sch<T, RES, SK, 2>(p, zero_page, s);
+  }
 }
 
 int launch_conv_wide(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {

@@ -1668,6 +1668,7 @@ extern "C" {
 
 const char* tango_last_error(void) { return tango::last_error(); }
 const char* tango_version(void) { return "tango-mi355x 0.1 (gfx950)"; }
+void tango_tuning_reload(void) { tango::tuning_reload(); }
 
 int tango_engine_create(const tango_config_t* cfg, tango_engine_t** out) {
   if (!cfg || !out) { tango::set_error("tango_engine_create: null argument"); return -1; }

@@ -15,11 +15,30 @@
 // mm/addmm (216), and the VAE / HiFi-GAN convolution + conv_transpose1d calls.
 #include <cstdlib>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "common.h"
 #include "gemm_device.h"
 #include "tuning.h"
 
 namespace tango {
+
+int ensure_dyn_lds(const void* kfn, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> opted;
+  int dev = 0;
+  TANGO_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  int& have = opted[std::make_pair(kfn, dev)];
+  if (bytes > have) {
+    TANGO_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    have = bytes;
+  }
+  return 0;
+}
+
 
 
 template <typename T, int BM, int BN, int BKB, int WM, int WN, int MODE>

@@ -215,11 +215,7 @@ template <typename T, int BN, int MODE>
 static int launch_dma_cfg(const GemmParams& p, hipStream_t s) {
   constexpr int LDS = 3 * (256 + BN) * 128;
   auto kfn = gemm_dma_kernel<T, BN, MODE, true>;     // ping-pong main loop (the lock-step variant is no longer compiled)
-  static bool attr_set = false;
-  if (!attr_set) {
-    TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
+  TANGO_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(kfn), LDS));
   const int MT = (p.M + 255) / 256, NT = (p.N + BN - 1) / BN;
   const int staged = (MODE != MODE_CONV1D && epilogue_can_stage<T>(p)) ? 1 : 0;
   const int pp_mode = 0;   // static half assignment: waves w and w + 4 share a SIMD (tools/simd_probe.hip)

@@ -53,13 +53,21 @@ template <typename T> __device__ __forceinline__ void wide_frag_stats(const u32x
   }
 }
 
-template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool SK>
+// SCH: where the LDS-DMAs of chunk kc+3 are issued (round 4; profiles/r4_*sched*):
+//   0  all at the head of the multiply part, before the first MFMA (rounds 2-3)
+//   1  all inside the MFMA stream, one DMA every eight MFMAs: the matrix pipe starts at once and covers the DMA issue
+//   2  two per wave in the READ part (after the fragment reads), the rest inside the MFMA stream
+//   3  all in the read part
+// 2 and 3 write the stage of chunk kc-1 one slot earlier than 0 / 1: the other half read it in the previous slot, so every wave
+// retires its fragment reads (lgkmcnt(0)) BEFORE the barrier that ends its read part.
+template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool SK, int SCH>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, const int pp_mode, unsigned long long* __restrict__ trace) {
   constexpr int BM = 256, BN = 320, CB = 64, NST = 4;
   constexpr int ROWS = BM + BN, STAGE = ROWS * CB;
   constexpr int RG = ROWS / 16;                  // 16-row groups (1 KiB) per stage: 36
   constexpr int RGW = (RG + 7) / 8;              // DMA instructions per wave per chunk: 5 (waves 0-3) or 4 (waves 4-7)
   constexpr int TM = 4, TN = 10;                 // wave tile 64 x 160; waves 4 (M) x 2 (N)
+  constexpr int NR = SCH == 2 ? 2 : SCH == 3 ? RGW : 0;   // DMAs of a chunk issued in the read part
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // NST stages
 
   // TANGO_WIDE_TRACE=1: wave 0 of every workgroup records 100 MHz timestamps at start / first chunk landed / loop end / end
@@ -98,25 +106,32 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
     nk = (nk < kc0 + per ? nk : kc0 + per) - kc0;
   }
   const int my_count = wave < RG - 8 * (RGW - 1) ? RGW : RGW - 1;      // wave-uniform
-  auto issue_chunk = [&](const int kc, const int st) {
-#pragma unroll
-    for (int i = 0; i < RGW; ++i) {
-      const int rg = wave + 8 * i;
-      if (rg < RG) {
-        const unsigned char* src = (i < 2 ? Ab : Wb) + r_base[i] + (int64_t)(kc0 + kc) * CB;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dsm + st * STAGE + rg * 1024), 16, 0, 0);
-      }
+  auto issue_one = [&](const int i, const int kc, const int st) {
+    const int rg = wave + 8 * i;
+    if (rg < RG) {
+      const unsigned char* src = (i < 2 ? Ab : Wb) + r_base[i] + (int64_t)(kc0 + kc) * CB;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dsm + st * STAGE + rg * 1024), 16, 0, 0);
     }
   };
-  // at most `chunks` whole chunks of this wave's DMAs may stay in flight
-  auto wait_inflight = [&](const int chunks) {
-    if (chunks <= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-    if (my_count == RGW) {
-      if (chunks == 1) wait_vmcnt_lit<RGW>();
-      else wait_vmcnt_lit<2 * RGW>();
-    } else {
-      if (chunks == 1) wait_vmcnt_lit<RGW - 1>();
-      else wait_vmcnt_lit<2 * (RGW - 1)>();
+  auto issue_chunk = [&](const int kc, const int st) {
+#pragma unroll
+    for (int i = 0; i < RGW; ++i) issue_one(i, kc, st);
+  };
+  // at most `chunks` whole chunks of this wave's DMAs, plus `extra` more, may stay in flight
+  auto wait_inflight = [&](const int chunks, const int extra) {
+    const int n = chunks * my_count + extra;   // wave-uniform, <= 2 * RGW
+    switch (n) {
+      case 0: wait_vmcnt_lit<0>(); break;
+      case 1: wait_vmcnt_lit<1>(); break;
+      case 2: wait_vmcnt_lit<2>(); break;
+      case 3: wait_vmcnt_lit<3>(); break;
+      case 4: wait_vmcnt_lit<4>(); break;
+      case 5: wait_vmcnt_lit<5>(); break;
+      case 6: wait_vmcnt_lit<6>(); break;
+      case 7: wait_vmcnt_lit<7>(); break;
+      case 8: wait_vmcnt_lit<8>(); break;
+      case 9: wait_vmcnt_lit<9>(); break;
+      default: wait_vmcnt_lit<10>(); break;
     }
   };
 
@@ -136,7 +151,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
   const int npro = nk < NST - 1 ? nk : NST - 1;
   for (int c = 0; c < npro; ++c) issue_chunk(c, c);
   const int half = pp_phase_half(wave, lane, (unsigned*)(dsm + (NST - 1) * STAGE), pp_mode);   // scratch: last stage, first DMA'd in the loop
-  wait_inflight(npro - 1);                              // chunk 0 landed
+  wait_inflight(npro - 1, 0);                           // chunk 0 landed
   pp_barrier();
 #ifdef TANGO_WIDE_TRACE_BUILD
   if (trace) t_first = __builtin_amdgcn_s_memrealtime();
@@ -145,16 +160,28 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
   int st = 0;
   for (int kc = 0; kc < nk; ++kc) {
     const unsigned char* Xs = dsm + st * STAGE;
+    const bool more = kc + NST - 1 < nk;               // chunk kc+3 exists: it refills the stage of chunk kc-1
+    const int st3 = st == 0 ? NST - 1 : st - 1;
     u32x4 wf[TN], xf[TM];
 #pragma unroll
     for (int a = 0; a < TN; ++a) wf[a] = *(const u32x4*)(Xs + wrow + a * 16 * CB);
 #pragma unroll
     for (int b = 0; b < TM; ++b) xf[b] = *(const u32x4*)(Xs + xrow + b * 16 * CB);
+    if (NR > 0) {
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) issue_one(i, kc + NST - 1, st3);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // see SCH above: the other half overwrites this stage from its next read part on
+    }
     // this wave's DMAs of chunk kc+1 must have landed before the barrier that precedes anyone's read of that chunk;
-    // chunk kc+2 (if issued) may stay in flight
-    if (kc + 1 < nk) wait_inflight(kc + 2 < nk ? 1 : 0);
+    // chunk kc+2 (if issued) and what this read part issued of chunk kc+3 may stay in flight
+    if (kc + 1 < nk) {
+      const int nr_mine = NR < my_count ? NR : my_count;
+      wait_inflight(kc + 2 < nk ? 1 : 0, more ? nr_mine : 0);
+    }
     pp_barrier();
-    if (kc + NST - 1 < nk) issue_chunk(kc + NST - 1, st == 0 ? NST - 1 : st - 1);   // refills the stage of chunk kc-1
+    if (SCH == 0 && more) issue_chunk(kc + NST - 1, st3);
     __builtin_amdgcn_s_setprio(1);
     if (LN) {
       // row statistics from the activation fragments this wave holds anyway (both column halves compute them: 32 VALU
@@ -163,9 +190,19 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
       for (int b = 0; b < TM; ++b) wide_frag_stats<T>(xf[b], ssum[b], ssq[b]);
     }
 #pragma unroll
-    for (int a = 0; a < TN; ++a)
+    for (int a = 0; a < TN; ++a) {
 #pragma unroll
       for (int b = 0; b < TM; ++b) Mma<T>::run(acc[a][b], wf[a], xf[b]);
+      if (SCH != 0 && (a & 1) == 0) {
+        // after MFMAs 4, 12, 20, 28, 36: the a / 2-th DMA of this part
+        const int i = NR + (a >> 1);
+        if (i < RGW) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) issue_one(i, kc + NST - 1, st3);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
     __builtin_amdgcn_s_setprio(0);
     pp_barrier();
     st = st == NST - 1 ? 0 : st + 1;
@@ -239,15 +276,11 @@ bool gemm_wide_ok(int dtype, const GemmParams& p) {
   return tuning().force_big_kernels || tiles >= 192;
 }
 
-template <typename T, bool GEGLU, bool RES, bool LN, bool VT = false, bool SK = false>
-static int launch_wide_cfg(const GemmParams& p, hipStream_t s) {
+template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool SK, int SCH>
+static int launch_wide_sch(const GemmParams& p, hipStream_t s) {
   constexpr int LDS = 4 * (256 + 320) * 64;
-  auto kfn = gemm_wide_kernel<T, GEGLU, RES, LN, VT, SK>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
+  auto kfn = gemm_wide_kernel<T, GEGLU, RES, LN, VT, SK, SCH>;
+  TANGO_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(kfn), LDS));
   const int pp_mode = 0;   // static half assignment: waves w and w + 4 share a SIMD (tools/simd_probe.hip)
   const unsigned grid = (unsigned)((p.M / 256) * (p.N / 320));
   unsigned long long* trace = nullptr;
@@ -277,6 +310,16 @@ static int launch_wide_cfg(const GemmParams& p, hipStream_t s) {
   }
 #endif
   return 0;
+}
+
+template <typename T, bool GEGLU, bool RES, bool LN, bool VT = false, bool SK = false>
+static int launch_wide_cfg(const GemmParams& p, hipStream_t s) {
+  switch (tuning().wide_sched) {
+    case 0: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 0>(p, s);
+    case 1: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 1>(p, s);
+    case 3: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 3>(p, s);
+    default: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 2>(p, s);
+  }
 }
 
 template <typename T>

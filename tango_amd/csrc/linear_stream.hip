@@ -354,12 +354,8 @@ static int stream_launch(const GemmParams& p, hipStream_t s) {
   constexpr int BN = TN * 16;
   constexpr int SROWS = 16;
   constexpr int LDS = BN * KS * 64 + 8 * SROWS * (BN * (int)sizeof(T) + 16) + 2 * BN * 4;   // weight panel + per-wave output staging + constants
-  static bool attr_set = false;
   auto kfn = lin_stream_kernel<T, KS, TN, LN, FIX>;
-  if (!attr_set) {
-    TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
+  TANGO_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(kfn), LDS));
   const int NP = p.N / BN;
   int rpx = 32 / NP;               // one workgroup per CU: 32 per XCD = NP panels x rpx row ranges
   if (rpx < 1) rpx = 1;

@@ -22,24 +22,33 @@ struct Tuning {
   bool no_small_tile;       // TANGO_NO_SMALL_TILE=1    A/B: 64 x 64 tiles for small-M linears out (back to split-K + reduce / the streaming kernel) (round 3)
   bool no_xattn_fused;      // TANGO_NO_XATTN_FUSED=1   A/B: fused cross-attention block kernel out (round 3)
   bool no_single_key;       // TANGO_NO_SINGLE_KEY=1    A/B: single-key (unconditional-row) cross-attention shortcut out (round 4)
+  int wide_sched;           // TANGO_WIDE_SCHED=0..3    A/B: where the 256 x 320 kernels issue their LDS-DMAs (gemm_wide.hip: SCH; default 2) (round 4)
 };
 
-inline const Tuning& tuning() {
-  static const Tuning t = [] {
-    auto on = [](const char* k) { const char* v = getenv(k); return v != nullptr && v[0] != '0'; };
-    Tuning x;
-    x.force_big_kernels = on("TANGO_FORCE_DMA_GEMM");
-    x.no_wide_conv = on("TANGO_NO_WIDE_CONV");
-    x.no_wide_gemm = on("TANGO_NO_WIDE_GEMM");
-    x.no_halo_conv = on("TANGO_NO_HALO_CONV");
-    x.no_dma_gemm = on("TANGO_NO_DMA_GEMM");
-    x.no_stream = on("TANGO_NO_STREAM");
-    x.no_small_tile = on("TANGO_NO_SMALL_TILE");
-    x.no_xattn_fused = on("TANGO_NO_XATTN_FUSED");
-    x.no_single_key = on("TANGO_NO_SINGLE_KEY");
-    return x;
-  }();
+inline Tuning read_tuning() {
+  auto on = [](const char* k) { const char* v = getenv(k); return v != nullptr && v[0] != '0'; };
+  Tuning x;
+  x.force_big_kernels = on("TANGO_FORCE_DMA_GEMM");
+  x.no_wide_conv = on("TANGO_NO_WIDE_CONV");
+  x.no_wide_gemm = on("TANGO_NO_WIDE_GEMM");
+  x.no_halo_conv = on("TANGO_NO_HALO_CONV");
+  x.no_dma_gemm = on("TANGO_NO_DMA_GEMM");
+  x.no_stream = on("TANGO_NO_STREAM");
+  x.no_small_tile = on("TANGO_NO_SMALL_TILE");
+  x.no_xattn_fused = on("TANGO_NO_XATTN_FUSED");
+  x.no_single_key = on("TANGO_NO_SINGLE_KEY");
+  const char* ws = getenv("TANGO_WIDE_SCHED");
+  x.wide_sched = (ws && ws[0] >= '0' && ws[0] <= '3') ? ws[0] - '0' : 2;
+  return x;
+}
+
+inline Tuning& tuning_storage() {
+  static Tuning t = read_tuning();
   return t;
 }
+inline const Tuning& tuning() { return tuning_storage(); }
+// measurement tools only (tango_tuning_reload): re-read the environment between A/B arms inside ONE process.  Switches that
+// plans bake in at build time (routing) only take effect for plans built afterwards; launch-time switches (wide_sched) at once.
+inline void tuning_reload() { tuning_storage() = read_tuning(); }
 
 }  // namespace tango

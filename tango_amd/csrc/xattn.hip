@@ -372,8 +372,7 @@ bool xattn_block_ok(int dtype, int C, int heads, int HW, int L, int64_t ldx, int
 }
 
 template <typename T> static int xa_launch(const XAttnParams& p, unsigned grid, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) { TANGO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_block_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS)); attr = true; }
+  TANGO_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(xattn_block_kernel<T>), XA_LDS));
   hipLaunchKernelGGL((xattn_block_kernel<T>), dim3(grid), dim3(512), XA_LDS, s, p);
   TANGO_HIP(hipGetLastError());
   return 0;
