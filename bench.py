@@ -95,7 +95,25 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `other_configs` sub-records (batch 1 / 8 and config 5's shard) the default config-3 run at N = 1 appends")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec this script under torch.distributed.run, one rank per GPU of this
+    node (rendezvous on 127.0.0.1, a free port).  Rank 0 of the child job prints the JSON line; its exit code is returned."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(args, unet_cfg, vae_cfg, hifi_cfg, sched_cfg):
@@ -148,62 +166,132 @@ def cpu_baseline(args, unet_cfg, vae_cfg, hifi_cfg, sched_cfg):
     }
 
 
+class Workload:
+    """One engine pair (UNet + VAE/vocoder) and the timed pass over it: the hot path for `batch` prompts per GPU."""
+
+    def __init__(self, args, device, xl, dtype, fp8):
+        from tango_amd.autoencoder import AutoencoderKL
+        from tango_amd.engine import UNET_CONFIG_LARGE, UNET_CONFIG_XL, VAE_CONFIG
+        from tango_amd.models import AudioDiffusion
+        from tango_amd.tango import Tango
+        self.unet_cfg = UNET_CONFIG_XL if xl else UNET_CONFIG_LARGE
+        self.model = AudioDiffusion(unet_config=self.unet_cfg, dtype=dtype, device=device, attn_fp8=fp8)
+        self.model.engine.load_synthetic(args.seed)
+        self.model.use_graph = not args.no_graph
+        self.vae = AutoencoderKL(ddconfig=dict(VAE_CONFIG, attn_resolutions=[]), embed_dim=8, scale_factor=VAE_CONFIG["scale_factor"],
+                                 dtype=dtype, device=device)
+        self.vae.engine.load_synthetic(args.seed)
+        self.tango = Tango.from_components(self.model, self.vae)
+        self.device = device
+        self.n_samples = self.vae.engine.vocoder_samples(1024)
+        self.denoise_ms = []
+
+    def compute(self, denoise_steps, guidance):
+        def fn(pe, pm, offset, seed):
+            b = pe.shape[0] // 2
+            # initial latents keyed by the GLOBAL sample index (like the step noise): outputs do not depend on the GPU count
+            lat = torch.stack([torch.randn(8, 256, 16, generator=torch.Generator(device="cpu").manual_seed(1000 + offset + i))
+                               for i in range(b)]).to(self.device)
+            latents = self.model.inference_from_embeddings(pe, pm, self.tango.scheduler, denoise_steps, guidance, latents=lat,
+                                                           seed=seed, sample_offset=offset)
+            mel = self.vae.decode_first_stage(latents)
+            wav = self.vae.engine.vocode(mel)            # int16 stays on the device; the gather moves it (no host round trip)
+            self.denoise_ms.append(self.model.engine.last_denoise_ms())
+            return wav
+        return fn
+
+
+def synthetic_text(Bg, L, d, device):
+    """synthetic text-encoder outputs: [uncond; cond], uncond mask = [1, 0, ...] (T5("") is one valid token)"""
+    g = torch.Generator().manual_seed(7)
+    cond = torch.randn(Bg, L, d, generator=g)
+    unc = torch.randn(Bg, L, d, generator=g)
+    mc = torch.ones(Bg, L, dtype=torch.bool)
+    mu = torch.zeros(Bg, L, dtype=torch.bool)
+    mu[:, 0] = True
+    return torch.cat([unc, cond]).to(device), torch.cat([mu, mc]).to(device)
+
+
+def timed_single_gpu(wl, args, batch, denoise_steps):
+    """one warm-up pass + one timed pass of the hot path on THIS GPU only (the `other_configs` sub-records)"""
+    from tango_amd.parallel import DataParallelGenerator
+    dp = DataParallelGenerator(wl.compute(denoise_steps, args.guidance), wl.device)
+    pe, pm = synthetic_text(batch, args.text_len, wl.unet_cfg["cross_attention_dim"], wl.device)
+    dp.generate(pe, pm, args.guidance, wl.n_samples, seed=args.seed)
+    wl.denoise_ms.clear()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wav = dp.generate(pe, pm, args.guidance, wl.n_samples, seed=args.seed)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert wav.shape == (batch, wl.n_samples)
+    per_step_ms = float(np.mean([m[1] for m in wl.denoise_ms]))
+    ach = GFLOP_UNET_PER_PROMPT_STEP * batch / per_step_ms
+    return {"value": batch * AUDIO_SECONDS_PER_SAMPLE / dt, "unit": "audio-seconds/s", "batch": batch, "denoise_steps": denoise_steps,
+            "seconds_per_pass": dt, "denoise_step_launch_ms": per_step_ms, "roofline_frac": ach / 2500.0}
+
+
+def stub_main(args, world, rank):
+    """TANGO_BENCH_STUB=1 (tests/test_bench_launch.py): the launch / rendezvous / sharding / gather / JSON plumbing of this
+    script on CPU over gloo with a stand-in compute function.  Not a measurement: the line says "stub": true."""
+    from tango_amd.parallel import DataParallelGenerator
+    device = torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_samples = 64
+
+    def compute(pe, pm, offset, seed):
+        b = pe.shape[0] // 2
+        return (torch.arange(b, dtype=torch.int16)[:, None] + offset).expand(b, n_samples).contiguous()
+
+    dp = DataParallelGenerator(compute, device)
+    B, L, d = args.batch, args.text_len, 8
+    Bg = B * world
+    pe, pm = synthetic_text(Bg, L, d, device) if rank == 0 else (None, None)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wav = dp.generate(pe, pm, args.guidance, n_samples, seed=args.seed)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        assert wav.shape == (Bg, n_samples) and (wav[:, 0] == np.arange(Bg)).all()
+        print(json.dumps({"metric": "stub", "stub": True, "value": Bg * args.steps / dt, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ranks": world, "config": {"global_batch": Bg}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
+    assert world == args.gpus, "--gpus %d but the launcher started %d ranks" % (args.gpus, world)
+    if os.environ.get("TANGO_BENCH_STUB"):
+        return stub_main(args, world, rank)
     torch.cuda.set_device(local_rank)          # before the process group: RCCL binds its communicator to the current device
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    from tango_amd.autoencoder import AutoencoderKL
-    from tango_amd.engine import HIFIGAN_CONFIG, UNET_CONFIG_LARGE, UNET_CONFIG_XL, VAE_CONFIG
-    from tango_amd.models import AudioDiffusion
+    from tango_amd.engine import HIFIGAN_CONFIG, VAE_CONFIG
     from tango_amd.parallel import DataParallelGenerator
     from tango_amd.scheduler import SD21_SCHEDULER_CONFIG
-    from tango_amd.tango import Tango
 
-    unet_cfg = UNET_CONFIG_XL if args.xl else UNET_CONFIG_LARGE
-    model = AudioDiffusion(unet_config=unet_cfg, dtype=args.dtype, device=device, attn_fp8=args.fp8_attn)
-    model.engine.load_synthetic(args.seed)
-    model.use_graph = not args.no_graph
-    vae = AutoencoderKL(ddconfig=dict(VAE_CONFIG, attn_resolutions=[]), embed_dim=8, scale_factor=VAE_CONFIG["scale_factor"],
-                        dtype=args.dtype, device=device)
-    vae.engine.load_synthetic(args.seed)
-    tango = Tango.from_components(model, vae)
-
+    wl = Workload(args, device, args.xl, args.dtype, args.fp8_attn)
+    unet_cfg, n_samples, denoise_ms = wl.unet_cfg, wl.n_samples, wl.denoise_ms
     B, L, d = args.batch, args.text_len, unet_cfg["cross_attention_dim"]
     Bg = B * world
-    n_samples = vae.engine.vocoder_samples(1024)
-    denoise_ms = []
 
-    def compute(pe, pm, offset, seed):
-        b = pe.shape[0] // 2
-        # initial latents keyed by the GLOBAL sample index (like the step noise): outputs do not depend on the GPU count
-        lat = torch.stack([torch.randn(8, 256, 16, generator=torch.Generator(device="cpu").manual_seed(1000 + offset + i))
-                           for i in range(b)]).to(device)
-        latents = model.inference_from_embeddings(pe, pm, tango.scheduler, args.denoise_steps, args.guidance, latents=lat,
-                                                  seed=seed, sample_offset=offset)
-        mel = vae.decode_first_stage(latents)
-        wav = vae.engine.vocode(mel)            # int16 stays on the device; the gather moves it (no host round trip)
-        denoise_ms.append(model.engine.last_denoise_ms())
-        return wav
-
-    dp = DataParallelGenerator(compute, device)
+    dp = DataParallelGenerator(wl.compute(args.denoise_steps, args.guidance), device)
     pe = pm = None
-    if rank == 0:   # synthetic text-encoder outputs: [uncond; cond], uncond mask = [1, 0, ...]
-        g = torch.Generator().manual_seed(7)
-        cond = torch.randn(Bg, L, d, generator=g)
-        unc = torch.randn(Bg, L, d, generator=g)
-        pe = torch.cat([unc, cond]).to(device)
-        mc = torch.ones(Bg, L, dtype=torch.bool)
-        mu = torch.zeros(Bg, L, dtype=torch.bool)
-        mu[:, 0] = True
-        pm = torch.cat([mu, mc]).to(device)
+    if rank == 0:
+        pe, pm = synthetic_text(Bg, L, d, device)
 
     def one_pass():
         return dp.generate(pe, pm, args.guidance, n_samples, seed=args.seed)
@@ -221,10 +309,12 @@ def main():
     if world > 1:
         dist.barrier(device_ids=[local_rank])
     dt = time.perf_counter() - t0
+    rccl_ranks = world
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor([dt, 1.0], device=device, dtype=torch.float64)
+        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)     # every rank that took part in the job over RCCL
+        dt, rccl_ranks = float(t[0].item()), int(round(float(t[1].item())))
 
     if rank == 0:
         assert wav.shape == (Bg, n_samples) and wav.dtype == np.int16
@@ -243,6 +333,7 @@ def main():
                                    "HiFi-GAN, %d prompts/GPU x %d tokens" % (workload_name(args), " XL" if args.xl else "", "891M" if args.xl else "866M", args.denoise_steps,
                                                                              args.guidance, " with fp8 P.V self-attention" if args.fp8_attn else "", B, L),
                        "global_batch": Bg, "text_len": L, "denoise_steps": args.denoise_steps, "parallelism": "dp%d" % world,
+                       "rccl_ranks": rccl_ranks,
                        "hipgraph": not args.no_graph, "fp8_attention": bool(args.fp8_attn), "kernel_src_sha16": kernel_source_sha16()},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                          "frac": ach / PEAK_TFLOPS[args.dtype],
@@ -252,6 +343,17 @@ def main():
             "end_to_end_tflops": (GFLOP_UNET_PER_PROMPT_STEP * args.denoise_steps + GFLOP_VAE_PER_SAMPLE + GFLOP_VOCODER_PER_SAMPLE)
                                  * Bg * args.steps / dt / 1000.0,
         }
+        if world == 1 and not args.no_other_configs and workload_name(args) == "BASELINE config 3":
+            # the other batch sizes north_star names, timed by the same process (one warm-up + one timed pass each, ~20 s in all):
+            # sub-records only -- `value` above stays config 3
+            oc = {}
+            oc["config2_b1_100step_fp16"] = timed_single_gpu(wl, args, 1, 100)
+            oc["b8_200step_fp16"] = timed_single_gpu(wl, args, 8, 200)
+            del wl
+            wl5 = Workload(args, device, True, "bf16", True)
+            oc["config5_shard_xl_bf16_fp8attn_b8_200step"] = timed_single_gpu(wl5, args, 8, 200)
+            del wl5
+            out["other_configs"] = oc
         if world == 1 and not args.no_cpu_baseline:
             keys = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "prediction_type", "clip_sample", "variance_type")
             out["cpu_baseline"] = cpu_baseline(args, unet_cfg, VAE_CONFIG, HIFIGAN_CONFIG, {k: SD21_SCHEDULER_CONFIG[k] for k in keys})

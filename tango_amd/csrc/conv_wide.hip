@@ -30,14 +30,17 @@ static constexpr int CW_HALO_MAX = 544;    // halo pixels per tile: 2 x 34 KiB h
 static constexpr int CW_NA = 5;            // halo DMA pieces (16 rows) per wave per channel chunk: 8 waves x 5 x 16 rows >= 544
 
 // SCH: where the LDS-DMAs of an item (one halo piece of the next chunk during taps 0..4, the weight rows of item i+3) are issued
-// (round 4, as in gemm_wide.hip):
+// (round 4, profiles/r4_c1_dma_schedule_ab_b32.txt; as in gemm_wide.hip):
 //   0  at the head of the multiply part, source offsets fetched from LDS there (rounds 2-3: two LDS round trips + the DMA issue
 //      in front of the first MFMA)
-//   1  inside the MFMA stream, one DMA every eight MFMAs; the source offsets are fetched in the read part
-//   2  halo piece + first weight group in the READ part, the other weight groups inside the MFMA stream
-//   3  everything in the read part
-// 2 and 3 overwrite the stage of item i-1 (and, at tap 0, the halo buffer of chunk cc-1) one slot earlier: every wave retires its
-// fragment reads (lgkmcnt(0)) before the barrier that ends its read part.
+//   1  inside the MFMA stream, one DMA every eight MFMAs; the halo offset is fetched in the read part        (convs -10 %)
+//   2  halo piece + first weight group at the very START of the read part (offsets already in registers: the halo offset of the
+//      next item is fetched during the multiply part), the other weight groups inside the MFMA stream
+//   3  as 1, but two DMAs back to back after MFMAs 8 and 24
+// (call 1 also measured "halo + first weight group AFTER the fragment reads" = no gain over 0, and "everything in the read
+//  part" = 9 % slower than 0: a DMA next to the fragment reads costs more than one among MFMAs, and the read part is not free.)
+// 2 overwrites the stage of item i-1 (and, at tap 0, the halo buffer of chunk cc-1) one slot earlier than the others: every wave
+// retires its fragment reads (lgkmcnt(0)) before the barrier that ends its read part.
 template <typename T, bool RES, bool SK, int SCH>
 __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, const unsigned char* zero_page, const int SR, const int nseg,
                                                            const int abytes) {
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
   constexpr int WRG = BN / 16;                  // 16-row DMA groups per weight item: 20
   constexpr int WRGW = (WRG + 7) / 8;           // per wave: 3 (waves 0-3) or 2
   constexpr int TM = 4, TN = 10;
-  constexpr int NRW = SCH == 2 ? 1 : SCH == 3 ? WRGW : 0;   // weight groups of an item issued in the read part
+  constexpr int NRW = SCH == 2 ? 1 : 0;         // weight groups of an item issued in the read part
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // [halo 0 | halo 1 | W stage 0..3]
   unsigned char* const As = dsm;
   unsigned char* const Ws = dsm + 2 * abytes;
@@ -186,6 +189,9 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
   if (half) pp_barrier();                           // the stagger: half B starts one slot late
   int st = 0, item = 0;
   int prev_h = 0;                                   // did the previous item issue a halo piece (it is younger than item i+1's weights)
+  unsigned hoff = SCH == 2 ? aoff_lds[0] : 0u;      // source offset of the next halo piece to issue (SCH 2: fetched an item ahead)
+  unsigned w_off0 = w_off0_init;                    // (one register; the rolled tap loop leaves room for it)
+  asm volatile("" : "+v"(w_off0));
   for (int cc = cc0; cc < cc1; ++cc) {
     const unsigned char* Ah = As + (cc & 1) * abytes;
     const bool more_c = cc + 1 < cc1;
@@ -204,10 +210,10 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
         koff3 = (t3 * p.Cin + c3 * BK) * (int)sizeof(T);
       }
       // ---- read part ----
-      unsigned hoff = 0, w_off0 = 0;
-      if (SCH != 0) {
-        if (iss_h) hoff = aoff_lds[tap * 512];
-        w_off0 = aoff_lds[CW_NA * 512];
+      if (SCH == 1 || SCH == 3) { if (iss_h) hoff = aoff_lds[tap * 512]; }
+      if (SCH == 2) {
+        if (iss_h) issue_a_off(tap, cc + 1, (cc + 1) & 1, hoff);
+        if (iss_w) issue_w_one(0, koff3, st3, w_off0);
       }
       u32x4 wf[TN], xf[TM];
 #pragma unroll
@@ -219,19 +225,12 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
         const int h = h0 + hs;
         xf[b] = *(const u32x4*)(Ah + h * CB + ((kg ^ ((h >> 1) & 2)) << 4));
       }
-      if (SCH >= 2) {
-        if (iss_h) issue_a_off(tap, cc + 1, (cc + 1) & 1, hoff);
-        if (iss_w) {
-#pragma unroll
-          for (int i = 0; i < NRW; ++i) issue_w_one(i, koff3, st3, w_off0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // see SCH above
-      }
+      if (SCH == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // see SCH above
       // item i+1 must have landed before the barrier that precedes anybody's read of it.  Younger than its last DMA, in issue
-      // order: [halo piece of item i-1] [weights of item i+2] and, SCH >= 2, [halo piece of this item] [read-part weights of item i+3]
+      // order: [halo piece of item i-1] [weights of item i+2] and, SCH 2, [halo piece of this item] [read-part weights of item i+3]
       if (item + 1 < NI) {
         int n = prev_h + (item + 2 < NI ? my_w : 0);
-        if (SCH >= 2) n += (iss_h ? 1 : 0) + (iss_w ? my_rw : 0);
+        if (SCH == 2) n += (iss_h ? 1 : 0) + (iss_w ? my_rw : 0);
         wait_n(n);
       }
       prev_h = iss_h ? 1 : 0;
@@ -242,6 +241,11 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
         const int t3 = tap + 3;
         if (t3 < 9) issue_w(t3, cc, st3);
         else if (more_c) issue_w(t3 - 9, cc + 1, st3);
+      }
+      if (SCH == 2) {
+        // the halo offset the NEXT item's read part starts with (an LDS read among MFMAs costs nothing there)
+        const int tn = tap + 1 < 9 ? tap + 1 : 0;
+        if (tn < CW_NA) hoff = aoff_lds[tn * 512];
       }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -257,6 +261,18 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
             else if (sl - 1 < WRGW) { if (iss_w) issue_w_one(sl - 1, koff3, st3, w_off0); }
           } else {
             if (NRW + sl < WRGW) { if (iss_w) issue_w_one(NRW + sl, koff3, st3, w_off0); }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (SCH == 3 && (a == 1 || a == 5)) {
+          // after MFMAs 8 and 24: [halo piece, weight group 0], [weight groups 1, 2]
+          __builtin_amdgcn_sched_barrier(0);
+          if (a == 1) {
+            if (iss_h) issue_a_off(tap, cc + 1, (cc + 1) & 1, hoff);
+            if (iss_w) issue_w_one(0, koff3, st3, w_off0);
+          } else if (iss_w) {
+#pragma unroll
+            for (int i = 1; i < WRGW; ++i) issue_w_one(i, koff3, st3, w_off0);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -352,9 +368,9 @@ template <typename T, bool RES, bool SK = false>
 static int launch_conv_wide_cfg(const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {
   switch (tuning().wide_sched) {
     case 0: return launch_conv_wide_sch<T, RES, SK, 0>(p, zero_page, s);
-    case 1: return launch_conv_wide_sch<T, RES, SK, 1>(p, zero_page, s);
+    case 2: return launch_conv_wide_sch<T, RES, SK, 2>(p, zero_page, s);
     case 3: return launch_conv_wide_sch<T, RES, SK, 3>(p, zero_page, s);
-    default: return launch_conv_wide_sch<T, RES, SK, 2>(p, zero_page, s);
+    default: return launch_conv_wide_sch<T, RES, SK, 1>(p, zero_page, s);
   }
 }
 

@@ -53,12 +53,12 @@ template <typename T> __device__ __forceinline__ void wide_frag_stats(const u32x
   }
 }
 
-// SCH: where the LDS-DMAs of chunk kc+3 are issued (round 4; profiles/r4_*sched*):
+// SCH: where the LDS-DMAs of chunk kc+3 are issued (round 4; profiles/r4_c1_dma_schedule_ab_b32.txt):
 //   0  all at the head of the multiply part, before the first MFMA (rounds 2-3)
 //   1  all inside the MFMA stream, one DMA every eight MFMAs: the matrix pipe starts at once and covers the DMA issue
-//   2  two per wave in the READ part (after the fragment reads), the rest inside the MFMA stream
-//   3  all in the read part
-// 2 and 3 write the stage of chunk kc-1 one slot earlier than 0 / 1: the other half read it in the previous slot, so every wave
+//   2  two per wave at the very START of the read part (before the fragment reads), the rest inside the MFMA stream
+//   3  as 1, but two DMAs back to back after MFMAs 8 and 24 (+ the fifth after 32)
+// 2 writes the stage of chunk kc-1 one slot earlier than the others: the other half read it in the previous slot, so every wave
 // retires its fragment reads (lgkmcnt(0)) BEFORE the barrier that ends its read part.
 template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool SK, int SCH>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, const int pp_mode, unsigned long long* __restrict__ trace) {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
   constexpr int RG = ROWS / 16;                  // 16-row groups (1 KiB) per stage: 36
   constexpr int RGW = (RG + 7) / 8;              // DMA instructions per wave per chunk: 5 (waves 0-3) or 4 (waves 4-7)
   constexpr int TM = 4, TN = 10;                 // wave tile 64 x 160; waves 4 (M) x 2 (N)
-  constexpr int NR = SCH == 2 ? 2 : SCH == 3 ? RGW : 0;   // DMAs of a chunk issued in the read part
+  constexpr int NR = SCH == 2 ? 2 : 0;           // DMAs of a chunk issued in the read part
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // NST stages
 
   // TANGO_WIDE_TRACE=1: wave 0 of every workgroup records 100 MHz timestamps at start / first chunk landed / loop end / end
@@ -162,18 +162,16 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
     const unsigned char* Xs = dsm + st * STAGE;
     const bool more = kc + NST - 1 < nk;               // chunk kc+3 exists: it refills the stage of chunk kc-1
     const int st3 = st == 0 ? NST - 1 : st - 1;
+    if (NR > 0 && more) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) issue_one(i, kc + NST - 1, st3);
+    }
     u32x4 wf[TN], xf[TM];
 #pragma unroll
     for (int a = 0; a < TN; ++a) wf[a] = *(const u32x4*)(Xs + wrow + a * 16 * CB);
 #pragma unroll
     for (int b = 0; b < TM; ++b) xf[b] = *(const u32x4*)(Xs + xrow + b * 16 * CB);
-    if (NR > 0) {
-      if (more) {
-#pragma unroll
-        for (int i = 0; i < NR; ++i) issue_one(i, kc + NST - 1, st3);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // see SCH above: the other half overwrites this stage from its next read part on
-    }
+    if (NR > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // see SCH above: the other half overwrites this stage from its next read part on
     // this wave's DMAs of chunk kc+1 must have landed before the barrier that precedes anyone's read of that chunk;
     // chunk kc+2 (if issued) and what this read part issued of chunk kc+3 may stay in flight
     if (kc + 1 < nk) {
@@ -193,7 +191,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
     for (int a = 0; a < TN; ++a) {
 #pragma unroll
       for (int b = 0; b < TM; ++b) Mma<T>::run(acc[a][b], wf[a], xf[b]);
-      if (SCH != 0 && (a & 1) == 0) {
+      if ((SCH == 1 || SCH == 2) && (a & 1) == 0) {
         // after MFMAs 4, 12, 20, 28, 36: the a / 2-th DMA of this part
         const int i = NR + (a >> 1);
         if (i < RGW) {
@@ -201,6 +199,15 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
           if (more) issue_one(i, kc + NST - 1, st3);
           __builtin_amdgcn_sched_barrier(0);
         }
+      }
+      if (SCH == 3 && (a == 1 || a == 5 || a == 7)) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+          if (a == 1) { issue_one(0, kc + NST - 1, st3); issue_one(1, kc + NST - 1, st3); }
+          else if (a == 5) { issue_one(2, kc + NST - 1, st3); issue_one(3, kc + NST - 1, st3); }
+          else if (RGW > 4) issue_one(4, kc + NST - 1, st3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -316,9 +323,9 @@ template <typename T, bool GEGLU, bool RES, bool LN, bool VT = false, bool SK = 
 static int launch_wide_cfg(const GemmParams& p, hipStream_t s) {
   switch (tuning().wide_sched) {
     case 0: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 0>(p, s);
-    case 1: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 1>(p, s);
+    case 2: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 2>(p, s);
     case 3: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 3>(p, s);
-    default: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 2>(p, s);
+    default: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 1>(p, s);
   }
 }
 

@@ -94,7 +94,7 @@ def test_config1_full_size_fp32():
     err = (lat - r["lat"]).abs().max().item()
     print("config 1 (866M UNet, B=1, 10 DDPM steps, g=3) fp32 engine vs oracle: latents max abs err %.3e (|ref| max %.2f)"
           % (err, r["lat"].abs().max()))
-    assert err <= 1e-2
+    assert err <= 2e-5           # measured 5.7e-6: floors are <= 3x the measured value
     merr = ((mel - r["mel"]).abs().max() / r["mel"].abs().max()).item()
     print("config 1 fp32: mel rel err %.3e, mel PSNR %.1f dB" % (merr, psnr(mel, r["mel"])))
     assert merr <= 1e-3
@@ -105,12 +105,12 @@ def test_config1_full_size_fp32():
     print("config 1 fp32: int16 from the oracle mel: <=1 LSB on %.5f (max %d); end-to-end waveform SNR %.1f dB"
           % (frac, d.max(), snr_db(wav, r["wav"])))
     assert w2.shape == (1, 163872) and frac >= 0.999
-    assert snr_db(wav, r["wav"]) >= 40.0
+    assert snr_db(wav, r["wav"]) >= 84.0          # measured 90.5 dB
 
 
-# measured on MI355X (round 2, recorded in DESIGN.md section 3): fp16 4.6e-3 / 70.5 dB / 47.7 dB, bf16 4.0e-2 / 52.3 dB / 29.7 dB;
-# the asserted floors leave ~8 dB (4x on the latents) of margin
-@pytest.mark.parametrize("dtype,lat_tol,mel_floor,wav_floor", [("fp16", 2e-2, 62.0, 39.0), ("bf16", 1.6e-1, 44.0, 21.0)])
+# measured on MI355X (rounds 2-3): fp16 4.6e-3 / 70.5 dB / 47.7 dB, bf16 3.6e-2 / 52.3 dB / 29.7 dB; the floors
+# are 3x on the latents and 6 dB (2x in amplitude) on the mel / waveform measures (no looser than 3x)
+@pytest.mark.parametrize("dtype,lat_tol,mel_floor,wav_floor", [("fp16", 1.4e-2, 64.5, 41.7), ("bf16", 1.1e-1, 46.3, 23.7)])
 def test_config1_reduced_precision_ladder(dtype, lat_tol, mel_floor, wav_floor):
     r = config1_reference()
     lat, mel, wav, _ = run_config1(dtype)
@@ -123,13 +123,13 @@ def test_config1_reduced_precision_ladder(dtype, lat_tol, mel_floor, wav_floor):
 def test_config5_precision_bf16_with_fp8_attention():
     """BASELINE config 5's precision ("bf16 + fp8 MFMA attention") on the full-size config-1 run: bf16 engine
     with the self-attention P.V products on the fp8 MFMA, against the fp32 oracle -- the same ladder as the bf16 row, so the
-    two lines in the log read as what the fp8 switch costs (floors leave ~6 dB of margin below the measured values)."""
+    two lines in the log read as what the fp8 switch costs.  Measured 3.7e-2 / 52.4 dB / 29.8 dB; floors 3x / 6 dB / 6 dB."""
     r = config1_reference()
     lat, mel, wav, _ = run_config1("bf16", attn_fp8=True)
     err = (lat - r["lat"]).abs().max().item()
     p, s = psnr(mel, r["mel"]), snr_db(wav, r["wav"])
     print("config 1 bf16 + fp8 P.V attention vs fp32 oracle: latents max abs err %.3e, mel PSNR %.1f dB, waveform SNR %.1f dB" % (err, p, s))
-    assert err <= 4e-1 and p >= 36.0 and s >= 14.0
+    assert err <= 1.1e-1 and p >= 46.4 and s >= 23.8
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
@@ -149,7 +149,7 @@ def test_unet_forward_xl(dtype):
     out = e.unet_forward(x.cuda(), 500, enc.cuda(), mask.cuda()).cpu()
     err = ((out - ref).abs().max() / ref.abs().max()).item()
     print("XL UNet (d_text 2048) %s rel err %.3e" % (dtype, err))
-    assert err <= (1e-3 if dtype == "fp32" else 3e-2)
+    assert err <= (5e-6 if dtype == "fp32" else 4.3e-3)     # measured 1.6e-6 / 1.4e-3
 
 
 def _philox(lib, B, C_, HW, step, seed, offset):
