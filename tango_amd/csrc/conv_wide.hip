@@ -29,18 +29,18 @@ static constexpr int CW_HALO_MAX = 544;    // halo pixels per tile: 2 x 34 KiB h
                                            // (544 = four 32 x 2 images with their borders: the UNet's level 3)
 static constexpr int CW_NA = 5;            // halo DMA pieces (16 rows) per wave per channel chunk: 8 waves x 5 x 16 rows >= 544
 
-// SCH: where the LDS-DMAs of an item (one halo piece of the next chunk during taps 0..4, the weight rows of item i+3) are issued
-// (round 4, profiles/r4_c1_dma_schedule_ab_b32.txt; as in gemm_wide.hip):
+// SCH: where the LDS-DMAs of an item (one halo piece of the next chunk during taps 0..4, the weight rows of item i+3) are issued,
+// and what else sits in the multiply part (round 4, as in gemm_wide.hip):
 //   0  at the head of the multiply part, source offsets fetched from LDS there (rounds 2-3: two LDS round trips + the DMA issue
 //      in front of the first MFMA)
-//   1  inside the MFMA stream, one DMA every eight MFMAs; the halo offset is fetched in the read part        (convs -10 %)
-//   2  halo piece + first weight group at the very START of the read part (offsets already in registers: the halo offset of the
-//      next item is fetched during the multiply part), the other weight groups inside the MFMA stream
-//   3  as 1, but two DMAs back to back after MFMAs 8 and 24
-// (call 1 also measured "halo + first weight group AFTER the fragment reads" = no gain over 0, and "everything in the read
-//  part" = 9 % slower than 0: a DMA next to the fragment reads costs more than one among MFMAs, and the read part is not free.)
-// 2 overwrites the stage of item i-1 (and, at tap 0, the halo buffer of chunk cc-1) one slot earlier than the others: every wave
-// retires its fragment reads (lgkmcnt(0)) before the barrier that ends its read part.
+//   1  inside the MFMA stream, one DMA after every eight MFMAs; the halo offset is fetched in the read part   (convs -10 %,
+//      profiles/r4_c1_dma_schedule_ab_b32.txt)
+//   2  as 1, with a LEAN multiply part: the wave-uniform inputs of the DMAs (three weight source bases as SGPR pairs, the two LDS
+//      destinations, the three "issue it" flags) and the 64-bit per-lane halo source are computed in the READ part and pinned in
+//      registers; a DMA costs [branch, m0, global_load_lds] among the MFMAs (the ISA of variant 1 has 58 non-MFMA instructions
+//      in the multiply part of an item, and an in-order wave hides only 1-2 issue slots behind a 16-cycle MFMA)
+// Also measured and dropped (call 1 / 2 of round 4): DMAs in the read part (after the fragment reads: = 0; at its very start,
+// from registers: = 0; all of them there: 9 % slower than 0), paired DMAs after MFMAs 8 and 24 (= 1).
 template <typename T, bool RES, bool SK, int SCH>
 __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, const unsigned char* zero_page, const int SR, const int nseg,
                                                            const int abytes) {
@@ -50,7 +50,6 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
   constexpr int WRG = BN / 16;                  // 16-row DMA groups per weight item: 20
   constexpr int WRGW = (WRG + 7) / 8;           // per wave: 3 (waves 0-3) or 2
   constexpr int TM = 4, TN = 10;
-  constexpr int NRW = SCH == 2 ? 1 : 0;         // weight groups of an item issued in the read part
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // [halo 0 | halo 1 | W stage 0..3]
   unsigned char* const As = dsm;
   unsigned char* const Ws = dsm + 2 * abytes;
@@ -102,9 +101,9 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
   const unsigned w_off0_init = (unsigned)(((int64_t)wrow_d * p.Kp) * (int64_t)sizeof(T) + ((slot ^ ((wrow_d >> 1) & 2)) * 16));
   aoff_lds[CW_NA * 512] = w_off0_init;
   const unsigned w_step = (unsigned)(128 * p.Kp * (int64_t)sizeof(T));
+  const unsigned lds_as = (unsigned)(uintptr_t)(lptr_t)As, lds_ws = (unsigned)(uintptr_t)(lptr_t)Ws;
   const unsigned char* const Wt = Wb + (int64_t)n0 * p.Kp * (int64_t)sizeof(T);
   const int my_w = wave < WRG - 8 * (WRGW - 1) ? WRGW : WRGW - 1;      // wave-uniform
-  const int my_rw = NRW < my_w ? NRW : my_w;                            // of them in the read part
 
   auto issue_a_off = [&](const int t, const int cc, const int buf, const unsigned off) {
     const unsigned char* src = off != ~0u ? Ab + (int64_t)cc * CB + off : zero_page;
@@ -189,7 +188,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
   if (half) pp_barrier();                           // the stagger: half B starts one slot late
   int st = 0, item = 0;
   int prev_h = 0;                                   // did the previous item issue a halo piece (it is younger than item i+1's weights)
-  unsigned hoff = SCH == 2 ? aoff_lds[0] : 0u;      // source offset of the next halo piece to issue (SCH 2: fetched an item ahead)
+  unsigned hoff = 0u;                               // source offset of the halo piece this item issues
   unsigned w_off0 = w_off0_init;                    // (one register; the rolled tap loop leaves room for it)
   asm volatile("" : "+v"(w_off0));
   for (int cc = cc0; cc < cc1; ++cc) {
@@ -210,11 +209,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
         koff3 = (t3 * p.Cin + c3 * BK) * (int)sizeof(T);
       }
       // ---- read part ----
-      if (SCH == 1 || SCH == 3) { if (iss_h) hoff = aoff_lds[tap * 512]; }
-      if (SCH == 2) {
-        if (iss_h) issue_a_off(tap, cc + 1, (cc + 1) & 1, hoff);
-        if (iss_w) issue_w_one(0, koff3, st3, w_off0);
-      }
+      if (SCH != 0) { if (iss_h) hoff = aoff_lds[tap * 512]; }
       u32x4 wf[TN], xf[TM];
 #pragma unroll
       for (int a = 0; a < TN; ++a) wf[a] = *(const u32x4*)(Wst + wfoff + a * 16 * CB);
@@ -225,14 +220,20 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
         const int h = h0 + hs;
         xf[b] = *(const u32x4*)(Ah + h * CB + ((kg ^ ((h >> 1) & 2)) << 4));
       }
-      if (SCH == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // see SCH above
-      // item i+1 must have landed before the barrier that precedes anybody's read of it.  Younger than its last DMA, in issue
-      // order: [halo piece of item i-1] [weights of item i+2] and, SCH 2, [halo piece of this item] [read-part weights of item i+3]
-      if (item + 1 < NI) {
-        int n = prev_h + (item + 2 < NI ? my_w : 0);
-        if (SCH == 2) n += (iss_h ? 1 : 0) + (iss_w ? my_rw : 0);
-        wait_n(n);
+      // SCH 2: everything the multiply part's DMAs need, computed and pinned HERE (hipcc otherwise sinks it between the MFMAs)
+      int f_h = sgpr_i32(iss_h ? 1 : 0), f_w = sgpr_i32(iss_w ? 1 : 0), f_w2 = sgpr_i32(iss_w && my_w == WRGW ? 1 : 0);
+      const unsigned char* wb0 = sgpr_ptr(Wt + koff3);
+      const unsigned char* wb1 = sgpr_ptr(wb0 + w_step);
+      const unsigned char* wb2 = sgpr_ptr(wb1 + w_step);
+      unsigned ldw = sgpr_u32(lds_ws + (unsigned)st3 * WST + (unsigned)wave * 1024u);
+      unsigned ldh = sgpr_u32(lds_as + (unsigned)((cc + 1) & 1) * abytes + (unsigned)(tap * 8 + wave) * 1024u);
+      const unsigned char* hsrc = hoff != ~0u ? Ab + (int64_t)(cc + 1) * CB + hoff : zero_page;
+      if (SCH == 2) {
+        asm volatile("" : "+s"(f_h), "+s"(f_w), "+s"(f_w2), "+s"(wb0), "+s"(wb1), "+s"(wb2), "+s"(ldw), "+s"(ldh), "+v"(hsrc));
       }
+      // item i+1 must have landed before the barrier that precedes anybody's read of it.  Younger than its last DMA, in issue
+      // order: [halo piece of item i-1] [weights of item i+2]
+      if (item + 1 < NI) wait_n(prev_h + (item + 2 < NI ? my_w : 0));
       prev_h = iss_h ? 1 : 0;
       pp_barrier();
       // ---- multiply part ----
@@ -242,37 +243,25 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
         if (t3 < 9) issue_w(t3, cc, st3);
         else if (more_c) issue_w(t3 - 9, cc + 1, st3);
       }
-      if (SCH == 2) {
-        // the halo offset the NEXT item's read part starts with (an LDS read among MFMAs costs nothing there)
-        const int tn = tap + 1 < 9 ? tap + 1 : 0;
-        if (tn < CW_NA) hoff = aoff_lds[tn * 512];
-      }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int a = 0; a < TN; ++a) {
 #pragma unroll
         for (int b = 0; b < TM; ++b) Mma<T>::run(acc[a][b], wf[a], xf[b]);
-        if ((SCH == 1 || SCH == 2) && (a & 1) == 0) {
-          // after MFMAs 4, 12, 20, 28: SCH 1 [halo piece, weight groups 0, 1, 2], SCH 2 [weight groups 1, 2]
+        if (SCH != 0 && (a & 1) == 0 && (a >> 1) <= WRGW) {
+          // after MFMAs 4, 12, 20, 28: [halo piece, weight groups 0, 1, 2]
           const int sl = a >> 1;
           __builtin_amdgcn_sched_barrier(0);
           if (SCH == 1) {
             if (sl == 0) { if (iss_h) issue_a_off(tap, cc + 1, (cc + 1) & 1, hoff); }
-            else if (sl - 1 < WRGW) { if (iss_w) issue_w_one(sl - 1, koff3, st3, w_off0); }
+            else if (iss_w) issue_w_one(sl - 1, koff3, st3, w_off0);
           } else {
-            if (NRW + sl < WRGW) { if (iss_w) issue_w_one(NRW + sl, koff3, st3, w_off0); }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (SCH == 3 && (a == 1 || a == 5)) {
-          // after MFMAs 8 and 24: [halo piece, weight group 0], [weight groups 1, 2]
-          __builtin_amdgcn_sched_barrier(0);
-          if (a == 1) {
-            if (iss_h) issue_a_off(tap, cc + 1, (cc + 1) & 1, hoff);
-            if (iss_w) issue_w_one(0, koff3, st3, w_off0);
-          } else if (iss_w) {
-#pragma unroll
-            for (int i = 1; i < WRGW; ++i) issue_w_one(i, koff3, st3, w_off0);
+            unsigned o = w_off0;
+            asm volatile("" : "+v"(o));     // zero-extension next to the use: [SGPR base + 32-bit VGPR offset] addressing, no 64-bit VALU add
+            if (sl == 0) { if (f_h) __builtin_amdgcn_global_load_lds((gptr_t)hsrc, (lptr_t)(uintptr_t)ldh, 16, 0, 0); }
+            else if (sl == 1) { if (f_w) __builtin_amdgcn_global_load_lds((gptr_t)(wb0 + o), (lptr_t)(uintptr_t)ldw, 16, 0, 0); }
+            else if (sl == 2) { if (f_w) __builtin_amdgcn_global_load_lds((gptr_t)(wb1 + o), (lptr_t)(uintptr_t)(ldw + 8192u), 16, 0, 0); }
+            else { if (f_w2) __builtin_amdgcn_global_load_lds((gptr_t)(wb2 + o), (lptr_t)(uintptr_t)(ldw + 16384u), 16, 0, 0); }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -368,9 +357,8 @@ template <typename T, bool RES, bool SK = false>
 static int launch_conv_wide_cfg(const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {
   switch (tuning().wide_sched) {
     case 0: return launch_conv_wide_sch<T, RES, SK, 0>(p, zero_page, s);
-    case 2: return launch_conv_wide_sch<T, RES, SK, 2>(p, zero_page, s);
-    case 3: return launch_conv_wide_sch<T, RES, SK, 3>(p, zero_page, s);
-    default: return launch_conv_wide_sch<T, RES, SK, 1>(p, zero_page, s);
+    case 1: return launch_conv_wide_sch<T, RES, SK, 1>(p, zero_page, s);
+    default: return launch_conv_wide_sch<T, RES, SK, 2>(p, zero_page, s);
   }
 }
 

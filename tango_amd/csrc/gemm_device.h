@@ -317,6 +317,16 @@ __device__ __forceinline__ int pp_phase_half(const int wave, const int lane, uns
   return __builtin_amdgcn_readfirstlane(rank & 1);
 }
 
+// wave-uniform values forced into SGPRs (v_readfirstlane folds away when the value already lives there): inputs of the
+// `asm volatile("" : "+s"(x))` pins that keep a computation in the phase it was written in
+__device__ __forceinline__ int sgpr_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned sgpr_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ const unsigned char* sgpr_ptr(const unsigned char* q) {
+  const uint64_t v = (uint64_t)(uintptr_t)q;
+  const unsigned lo = sgpr_u32((unsigned)v), hi = sgpr_u32((unsigned)(v >> 32));
+  return (const unsigned char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt_lit() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // raw workgroup barrier (no vmcnt drain: LDS-DMAs stay in flight across it) that the scheduler may not move code across

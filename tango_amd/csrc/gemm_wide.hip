@@ -53,13 +53,16 @@ template <typename T> __device__ __forceinline__ void wide_frag_stats(const u32x
   }
 }
 
-// SCH: where the LDS-DMAs of chunk kc+3 are issued (round 4; profiles/r4_c1_dma_schedule_ab_b32.txt):
+// SCH: where the LDS-DMAs of chunk kc+3 are issued, and what else sits in the multiply part (round 4):
 //   0  all at the head of the multiply part, before the first MFMA (rounds 2-3)
-//   1  all inside the MFMA stream, one DMA every eight MFMAs: the matrix pipe starts at once and covers the DMA issue
-//   2  two per wave at the very START of the read part (before the fragment reads), the rest inside the MFMA stream
-//   3  as 1, but two DMAs back to back after MFMAs 8 and 24 (+ the fifth after 32)
-// 2 writes the stage of chunk kc-1 one slot earlier than the others: the other half read it in the previous slot, so every wave
-// retires its fragment reads (lgkmcnt(0)) BEFORE the barrier that ends its read part.
+//   1  inside the MFMA stream, one DMA after every eight MFMAs: the matrix pipe starts at once and covers the DMA issue
+//      (profiles/r4_c1_dma_schedule_ab_b32.txt: wide linears -2...-5 %, wide convs -10 %)
+//   2  as 1, with a LEAN multiply part: everything wave-uniform a DMA needs (source base of the chunk as an SGPR pair, LDS
+//      destination, "is there a chunk kc+3") is computed in the READ part and pinned in SGPRs, and the per-lane source is a
+//      32-bit offset from the tile's first row -- a DMA costs [branch, m0, global_load_lds v, s[..]] in the MFMA stream
+//      instead of ~8-11 instructions (an in-order wave hides only 1-2 issue slots behind a 16-cycle MFMA: the ISA of variant 1
+//      has ~45 non-MFMA instructions in the multiply part of a chunk)
+// Also measured and dropped: DMAs in the read part (before or after the fragment reads: no gain / -9 %), paired DMAs (= 1).
 template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool SK, int SCH>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, const int pp_mode, unsigned long long* __restrict__ trace) {
   constexpr int BM = 256, BN = 320, CB = 64, NST = 4;
@@ -67,7 +70,6 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
   constexpr int RG = ROWS / 16;                  // 16-row groups (1 KiB) per stage: 36
   constexpr int RGW = (RG + 7) / 8;              // DMA instructions per wave per chunk: 5 (waves 0-3) or 4 (waves 4-7)
   constexpr int TM = 4, TN = 10;                 // wave tile 64 x 160; waves 4 (M) x 2 (N)
-  constexpr int NR = SCH == 2 ? 2 : 0;           // DMAs of a chunk issued in the read part
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // NST stages
 
   // TANGO_WIDE_TRACE=1: wave 0 of every workgroup records 100 MHz timestamps at start / first chunk landed / loop end / end
@@ -89,14 +91,15 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
   // ---- DMA source rows: row group rg = wave + 8 i; i < 2 are activation rows (rg < 16), i >= 2 weight rows, for every wave ----
   const int lrow = lane >> 2;
   const int pc = (lane & 3) ^ ((4 - (lrow >> 2)) & 3);
-  const unsigned char* Ab = (const unsigned char*)p.A;
-  const unsigned char* Wb = (const unsigned char*)p.W;
-  int64_t r_base[RGW];
+  // wave-uniform bases of this tile's first activation / weight row; per-lane 32-bit offsets from them (256 / 320 rows: < 4 GiB)
+  const unsigned char* const At = (const unsigned char*)p.A + (int64_t)m0 * p.lda * (int64_t)sizeof(T);
+  const unsigned char* const Wt = (const unsigned char*)p.W + (int64_t)n0 * p.Kp * (int64_t)sizeof(T);
+  unsigned r_off[RGW];
 #pragma unroll
   for (int i = 0; i < RGW; ++i) {
     const int row = (wave + 8 * i) * 16 + lrow;
-    r_base[i] = i < 2 ? ((int64_t)(m0 + row) * p.lda) * (int64_t)sizeof(T) + pc * 16
-                      : ((int64_t)(n0 + row - BM) * p.Kp) * (int64_t)sizeof(T) + pc * 16;
+    r_off[i] = i < 2 ? (unsigned)((int64_t)row * p.lda * (int64_t)sizeof(T)) + pc * 16
+                     : (unsigned)((int64_t)(row - BM) * p.Kp * (int64_t)sizeof(T)) + pc * 16;
   }
   // split-K (plain epilogue only): blockIdx.y takes a contiguous range of k-chunks, partial tiles go to the workspace
   int kc0 = 0, nk = (p.K * (int)sizeof(T)) / CB;
@@ -106,32 +109,30 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
     nk = (nk < kc0 + per ? nk : kc0 + per) - kc0;
   }
   const int my_count = wave < RG - 8 * (RGW - 1) ? RGW : RGW - 1;      // wave-uniform
-  auto issue_one = [&](const int i, const int kc, const int st) {
-    const int rg = wave + 8 * i;
-    if (rg < RG) {
-      const unsigned char* src = (i < 2 ? Ab : Wb) + r_base[i] + (int64_t)(kc0 + kc) * CB;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dsm + st * STAGE + rg * 1024), 16, 0, 0);
-    }
+  const bool has5 = my_count == RGW;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
+  // one DMA: rows of group wave + 8 i of chunk (source bases sa / sw already at the chunk's k offset) into the stage at LDS byte ldst
+  auto dma = [&](const int i, const unsigned char* sa, const unsigned char* sw, const unsigned ldst) {
+    unsigned o = r_off[i];
+    asm volatile("" : "+v"(o));     // zero-extension next to the use: hipcc then picks the [SGPR base + 32-bit VGPR offset] form
+    __builtin_amdgcn_global_load_lds((gptr_t)((i < 2 ? sa : sw) + o), (lptr_t)(uintptr_t)(ldst + (unsigned)i * 8192u), 16, 0, 0);   // ldst: the wave's first group in the stage
   };
   auto issue_chunk = [&](const int kc, const int st) {
+    const unsigned char* sa = At + (int64_t)(kc0 + kc) * CB;
+    const unsigned char* sw = Wt + (int64_t)(kc0 + kc) * CB;
 #pragma unroll
-    for (int i = 0; i < RGW; ++i) issue_one(i, kc, st);
+    for (int i = 0; i < RGW; ++i)
+      if (i < RGW - 1 || has5) dma(i, sa, sw, lds0 + st * STAGE + (unsigned)wave * 1024u);
   };
-  // at most `chunks` whole chunks of this wave's DMAs, plus `extra` more, may stay in flight
-  auto wait_inflight = [&](const int chunks, const int extra) {
-    const int n = chunks * my_count + extra;   // wave-uniform, <= 2 * RGW
-    switch (n) {
-      case 0: wait_vmcnt_lit<0>(); break;
-      case 1: wait_vmcnt_lit<1>(); break;
-      case 2: wait_vmcnt_lit<2>(); break;
-      case 3: wait_vmcnt_lit<3>(); break;
-      case 4: wait_vmcnt_lit<4>(); break;
-      case 5: wait_vmcnt_lit<5>(); break;
-      case 6: wait_vmcnt_lit<6>(); break;
-      case 7: wait_vmcnt_lit<7>(); break;
-      case 8: wait_vmcnt_lit<8>(); break;
-      case 9: wait_vmcnt_lit<9>(); break;
-      default: wait_vmcnt_lit<10>(); break;
+  // at most `chunks` whole chunks of this wave's DMAs may stay in flight
+  auto wait_inflight = [&](const int chunks) {
+    if (chunks <= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+    if (has5) {
+      if (chunks == 1) wait_vmcnt_lit<RGW>();
+      else wait_vmcnt_lit<2 * RGW>();
+    } else {
+      if (chunks == 1) wait_vmcnt_lit<RGW - 1>();
+      else wait_vmcnt_lit<2 * (RGW - 1)>();
     }
   };
 
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
   const int npro = nk < NST - 1 ? nk : NST - 1;
   for (int c = 0; c < npro; ++c) issue_chunk(c, c);
   const int half = pp_phase_half(wave, lane, (unsigned*)(dsm + (NST - 1) * STAGE), pp_mode);   // scratch: last stage, first DMA'd in the loop
-  wait_inflight(npro - 1, 0);                           // chunk 0 landed
+  wait_inflight(npro - 1);                              // chunk 0 landed
   pp_barrier();
 #ifdef TANGO_WIDE_TRACE_BUILD
   if (trace) t_first = __builtin_amdgcn_s_memrealtime();
@@ -160,25 +161,27 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
   int st = 0;
   for (int kc = 0; kc < nk; ++kc) {
     const unsigned char* Xs = dsm + st * STAGE;
-    const bool more = kc + NST - 1 < nk;               // chunk kc+3 exists: it refills the stage of chunk kc-1
-    const int st3 = st == 0 ? NST - 1 : st - 1;
-    if (NR > 0 && more) {
-#pragma unroll
-      for (int i = 0; i < NR; ++i) issue_one(i, kc + NST - 1, st3);
-    }
+    const int st3 = st == 0 ? NST - 1 : st - 1;        // chunk kc+3 refills the stage of chunk kc-1
+    // ---- read part ----
     u32x4 wf[TN], xf[TM];
 #pragma unroll
     for (int a = 0; a < TN; ++a) wf[a] = *(const u32x4*)(Xs + wrow + a * 16 * CB);
 #pragma unroll
     for (int b = 0; b < TM; ++b) xf[b] = *(const u32x4*)(Xs + xrow + b * 16 * CB);
-    if (NR > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // see SCH above: the other half overwrites this stage from its next read part on
-    // this wave's DMAs of chunk kc+1 must have landed before the barrier that precedes anyone's read of that chunk;
-    // chunk kc+2 (if issued) and what this read part issued of chunk kc+3 may stay in flight
-    if (kc + 1 < nk) {
-      const int nr_mine = NR < my_count ? NR : my_count;
-      wait_inflight(kc + 2 < nk ? 1 : 0, more ? nr_mine : 0);
+    // what the multiply part's DMAs need, wave-uniform, pinned HERE (hipcc otherwise sinks these computations between the MFMAs)
+    int more = sgpr_i32(kc + NST - 1 < nk ? 1 : 0);
+    int more5 = sgpr_i32(more && has5 ? 1 : 0);
+    const unsigned char* sa = sgpr_ptr(At + (int64_t)(kc0 + kc + NST - 1) * CB);
+    const unsigned char* sw = sgpr_ptr(Wt + (int64_t)(kc0 + kc + NST - 1) * CB);
+    unsigned ldst = sgpr_u32(lds0 + st3 * STAGE + (unsigned)wave * 1024u);
+    if (SCH == 2) {
+      asm volatile("" : "+s"(more), "+s"(more5), "+s"(sa), "+s"(sw), "+s"(ldst));
     }
+    // this wave's DMAs of chunk kc+1 must have landed before the barrier that precedes anyone's read of that chunk;
+    // chunk kc+2 (if issued) may stay in flight
+    if (kc + 1 < nk) wait_inflight(kc + 2 < nk ? 1 : 0);
     pp_barrier();
+    // ---- multiply part ----
     if (SCH == 0 && more) issue_chunk(kc + NST - 1, st3);
     __builtin_amdgcn_s_setprio(1);
     if (LN) {
@@ -191,22 +194,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
     for (int a = 0; a < TN; ++a) {
 #pragma unroll
       for (int b = 0; b < TM; ++b) Mma<T>::run(acc[a][b], wf[a], xf[b]);
-      if ((SCH == 1 || SCH == 2) && (a & 1) == 0) {
-        // after MFMAs 4, 12, 20, 28, 36: the a / 2-th DMA of this part
-        const int i = NR + (a >> 1);
-        if (i < RGW) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (more) issue_one(i, kc + NST - 1, st3);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      if (SCH == 3 && (a == 1 || a == 5 || a == 7)) {
+      if (SCH != 0 && (a & 1) == 0) {
+        // after MFMAs 4, 12, 20, 28, 36: the a / 2-th DMA of chunk kc+3
+        const int i = a >> 1;
         __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-          if (a == 1) { issue_one(0, kc + NST - 1, st3); issue_one(1, kc + NST - 1, st3); }
-          else if (a == 5) { issue_one(2, kc + NST - 1, st3); issue_one(3, kc + NST - 1, st3); }
-          else if (RGW > 4) issue_one(4, kc + NST - 1, st3);
-        }
+        if (i < RGW - 1 ? more : more5) dma(i, sa, sw, ldst);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -323,9 +315,8 @@ template <typename T, bool GEGLU, bool RES, bool LN, bool VT = false, bool SK = 
 static int launch_wide_cfg(const GemmParams& p, hipStream_t s) {
   switch (tuning().wide_sched) {
     case 0: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 0>(p, s);
-    case 2: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 2>(p, s);
-    case 3: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 3>(p, s);
-    default: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 1>(p, s);
+    case 1: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 1>(p, s);
+    default: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 2>(p, s);
   }
 }
 

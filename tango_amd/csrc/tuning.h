@@ -22,7 +22,7 @@ struct Tuning {
   bool no_small_tile;       // TANGO_NO_SMALL_TILE=1    A/B: 64 x 64 tiles for small-M linears out (back to split-K + reduce / the streaming kernel) (round 3)
   bool no_xattn_fused;      // TANGO_NO_XATTN_FUSED=1   A/B: fused cross-attention block kernel out (round 3)
   bool no_single_key;       // TANGO_NO_SINGLE_KEY=1    A/B: single-key (unconditional-row) cross-attention shortcut out (round 4)
-  int wide_sched;           // TANGO_WIDE_SCHED=0..3    A/B: where the 256 x 320 kernels issue their LDS-DMAs (gemm_wide.hip: SCH; default 1) (round 4)
+  int wide_sched;           // TANGO_WIDE_SCHED=0..2    A/B: where the 256 x 320 kernels issue their LDS-DMAs (gemm_wide.hip: SCH; default 2) (round 4)
 };
 
 inline Tuning read_tuning() {
@@ -38,7 +38,7 @@ inline Tuning read_tuning() {
   x.no_xattn_fused = on("TANGO_NO_XATTN_FUSED");
   x.no_single_key = on("TANGO_NO_SINGLE_KEY");
   const char* ws = getenv("TANGO_WIDE_SCHED");
-  x.wide_sched = (ws && ws[0] >= '0' && ws[0] <= '3') ? ws[0] - '0' : 1;
+  x.wide_sched = (ws && ws[0] >= '0' && ws[0] <= '2') ? ws[0] - '0' : 2;
   return x;
 }
 
