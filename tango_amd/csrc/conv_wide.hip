@@ -29,21 +29,19 @@ static constexpr int CW_HALO_MAX = 544;    // halo pixels per tile: 2 x 34 KiB h
                                            // (544 = four 32 x 2 images with their borders: the UNet's level 3)
 static constexpr int CW_NA = 5;            // halo DMA pieces (16 rows) per wave per channel chunk: 8 waves x 5 x 16 rows >= 544
 
-// SCH: where the LDS-DMAs of an item (one halo piece of the next chunk during taps 0..4, the weight rows of item i+3) are issued,
-// and what else sits in the multiply part (round 4, as in gemm_wide.hip):
+// SCH: where the LDS-DMAs of an item (one halo piece of the next chunk during taps 0..4, the weight rows of item i+3) are issued
+// (round 4, as in gemm_wide.hip):
 //   0  at the head of the multiply part, source offsets fetched from LDS there (rounds 2-3: two LDS round trips + the DMA issue
 //      in front of the first MFMA)
 //   1  inside the MFMA stream, one DMA after every eight MFMAs; the halo offset is fetched in the read part   (convs -10 %,
 //      profiles/r4_c1_dma_schedule_ab_b32.txt)
-//   2  as 1, with a LEAN multiply part: the wave-uniform inputs of the DMAs (three weight source bases as SGPR pairs, the two LDS
-//      destinations, the three "issue it" flags) and the 64-bit per-lane halo source are computed in the READ part and pinned in
-//      registers; a DMA costs [branch, m0, global_load_lds] among the MFMAs (the ISA of variant 1 has 58 non-MFMA instructions
-//      in the multiply part of an item, and an in-order wave hides only 1-2 issue slots behind a 16-cycle MFMA)
-// Also measured and dropped (call 1 / 2 of round 4): DMAs in the read part (after the fragment reads: = 0; at its very start,
-// from registers: = 0; all of them there: 9 % slower than 0), paired DMAs after MFMAs 8 and 24 (= 1).
+// Measured and dropped (calls 1, 2, 4 of round 4, profiles/r4_c*): DMAs in the read part (after the fragment reads: = 0; at its
+// very start, from registers: = 0; all of them there: 9 % slower than 0), paired DMAs after MFMAs 8 and 24 (= 1), a "lean"
+// multiply part with the scalar address preparation pinned in the read part (5 % slower than 1), 32x32x16 MFMAs (probe: -5 %).
+// PRIO: see gemm_wide.hip.
 template <typename T, bool RES, bool SK, int SCH>
 __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, const unsigned char* zero_page, const int SR, const int nseg,
-                                                           const int abytes) {
+                                                           const int abytes, const int prio) {
   constexpr int BM = 256, BN = 320, CB = 64, NST = 4;
   constexpr int BK = CB / (int)sizeof(T);       // 32 channels per chunk
   constexpr int WST = BN * CB;                  // bytes per weight stage
@@ -101,7 +99,6 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
   const unsigned w_off0_init = (unsigned)(((int64_t)wrow_d * p.Kp) * (int64_t)sizeof(T) + ((slot ^ ((wrow_d >> 1) & 2)) * 16));
   aoff_lds[CW_NA * 512] = w_off0_init;
   const unsigned w_step = (unsigned)(128 * p.Kp * (int64_t)sizeof(T));
-  const unsigned lds_as = (unsigned)(uintptr_t)(lptr_t)As, lds_ws = (unsigned)(uintptr_t)(lptr_t)Ws;
   const unsigned char* const Wt = Wb + (int64_t)n0 * p.Kp * (int64_t)sizeof(T);
   const int my_w = wave < WRG - 8 * (WRGW - 1) ? WRGW : WRGW - 1;      // wave-uniform
 
@@ -186,6 +183,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
   wait_n(2 * my_w);
   pp_barrier();
   if (half) pp_barrier();                           // the stagger: half B starts one slot late
+  if (prio == 2 && half) __builtin_amdgcn_s_setprio(1);
   int st = 0, item = 0;
   int prev_h = 0;                                   // did the previous item issue a halo piece (it is younger than item i+1's weights)
   unsigned hoff = 0u;                               // source offset of the halo piece this item issues
@@ -220,17 +218,6 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
         const int h = h0 + hs;
         xf[b] = *(const u32x4*)(Ah + h * CB + ((kg ^ ((h >> 1) & 2)) << 4));
       }
-      // SCH 2: everything the multiply part's DMAs need, computed and pinned HERE (hipcc otherwise sinks it between the MFMAs)
-      int f_h = sgpr_i32(iss_h ? 1 : 0), f_w = sgpr_i32(iss_w ? 1 : 0), f_w2 = sgpr_i32(iss_w && my_w == WRGW ? 1 : 0);
-      const unsigned char* wb0 = sgpr_ptr(Wt + koff3);
-      const unsigned char* wb1 = sgpr_ptr(wb0 + w_step);
-      const unsigned char* wb2 = sgpr_ptr(wb1 + w_step);
-      unsigned ldw = sgpr_u32(lds_ws + (unsigned)st3 * WST + (unsigned)wave * 1024u);
-      unsigned ldh = sgpr_u32(lds_as + (unsigned)((cc + 1) & 1) * abytes + (unsigned)(tap * 8 + wave) * 1024u);
-      const unsigned char* hsrc = hoff != ~0u ? Ab + (int64_t)(cc + 1) * CB + hoff : zero_page;
-      if (SCH == 2) {
-        asm volatile("" : "+s"(f_h), "+s"(f_w), "+s"(f_w2), "+s"(wb0), "+s"(wb1), "+s"(wb2), "+s"(ldw), "+s"(ldh), "+v"(hsrc));
-      }
       // item i+1 must have landed before the barrier that precedes anybody's read of it.  Younger than its last DMA, in issue
       // order: [halo piece of item i-1] [weights of item i+2]
       if (item + 1 < NI) wait_n(prev_h + (item + 2 < NI ? my_w : 0));
@@ -243,7 +230,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
         if (t3 < 9) issue_w(t3, cc, st3);
         else if (more_c) issue_w(t3 - 9, cc + 1, st3);
       }
-      __builtin_amdgcn_s_setprio(1);
+      if (prio == 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int a = 0; a < TN; ++a) {
 #pragma unroll
@@ -252,26 +239,18 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
           // after MFMAs 4, 12, 20, 28: [halo piece, weight groups 0, 1, 2]
           const int sl = a >> 1;
           __builtin_amdgcn_sched_barrier(0);
-          if (SCH == 1) {
-            if (sl == 0) { if (iss_h) issue_a_off(tap, cc + 1, (cc + 1) & 1, hoff); }
-            else if (iss_w) issue_w_one(sl - 1, koff3, st3, w_off0);
-          } else {
-            unsigned o = w_off0;
-            asm volatile("" : "+v"(o));     // zero-extension next to the use: [SGPR base + 32-bit VGPR offset] addressing, no 64-bit VALU add
-            if (sl == 0) { if (f_h) __builtin_amdgcn_global_load_lds((gptr_t)hsrc, (lptr_t)(uintptr_t)ldh, 16, 0, 0); }
-            else if (sl == 1) { if (f_w) __builtin_amdgcn_global_load_lds((gptr_t)(wb0 + o), (lptr_t)(uintptr_t)ldw, 16, 0, 0); }
-            else if (sl == 2) { if (f_w) __builtin_amdgcn_global_load_lds((gptr_t)(wb1 + o), (lptr_t)(uintptr_t)(ldw + 8192u), 16, 0, 0); }
-            else { if (f_w2) __builtin_amdgcn_global_load_lds((gptr_t)(wb2 + o), (lptr_t)(uintptr_t)(ldw + 16384u), 16, 0, 0); }
-          }
+          if (sl == 0) { if (iss_h) issue_a_off(tap, cc + 1, (cc + 1) & 1, hoff); }
+          else if (iss_w) issue_w_one(sl - 1, koff3, st3, w_off0);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      __builtin_amdgcn_s_setprio(0);
+      if (prio == 0) __builtin_amdgcn_s_setprio(0);
       pp_barrier();
       st = st == NST - 1 ? 0 : st + 1;
     }
   }
   if (!half) pp_barrier();
+  if (prio == 2) __builtin_amdgcn_s_setprio(0);
   __syncthreads();   // every wave is past its last fragment read: the halo / weight LDS becomes the staging area
   unsigned char* const slice = dsm + wave * (WIDE_STAGE_BYTES + 1280);
   if (SK) {
@@ -347,7 +326,7 @@ static int launch_conv_wide_sch(const GemmParams& p, const unsigned char* zero_p
   auto kfn = conv3x3_wide_kernel<T, RES, SK, SCH>;
   TANGO_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(kfn), lds));
   const int tiles = (p.M / 256) * (p.N / 320);
-  hipLaunchKernelGGL(kfn, dim3((unsigned)tiles, (unsigned)(p.splitk > 1 ? p.splitk : 1)), dim3(512), lds, s, p, zero_page, g.SR, g.nseg, abytes);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)tiles, (unsigned)(p.splitk > 1 ? p.splitk : 1)), dim3(512), lds, s, p, zero_page, g.SR, g.nseg, abytes, tuning().wide_prio);
   TANGO_HIP(hipGetLastError());
   if (p.splitk > 1) TANGO_TRY(launch_splitk_reduce(TypeTag<T>::dt, p, s));
   return 0;
@@ -357,8 +336,7 @@ template <typename T, bool RES, bool SK = false>
 static int launch_conv_wide_cfg(const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {
   switch (tuning().wide_sched) {
     case 0: return launch_conv_wide_sch<T, RES, SK, 0>(p, zero_page, s);
-    case 1: return launch_conv_wide_sch<T, RES, SK, 1>(p, zero_page, s);
-    default: return launch_conv_wide_sch<T, RES, SK, 2>(p, zero_page, s);
+    default: return launch_conv_wide_sch<T, RES, SK, 1>(p, zero_page, s);
   }
 }
 

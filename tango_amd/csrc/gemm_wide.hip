@@ -53,18 +53,17 @@ template <typename T> __device__ __forceinline__ void wide_frag_stats(const u32x
   }
 }
 
-// SCH: where the LDS-DMAs of chunk kc+3 are issued, and what else sits in the multiply part (round 4):
+// SCH: where the LDS-DMAs of chunk kc+3 are issued (round 4):
 //   0  all at the head of the multiply part, before the first MFMA (rounds 2-3)
 //   1  inside the MFMA stream, one DMA after every eight MFMAs: the matrix pipe starts at once and covers the DMA issue
 //      (profiles/r4_c1_dma_schedule_ab_b32.txt: wide linears -2...-5 %, wide convs -10 %)
-//   2  as 1, with a LEAN multiply part: everything wave-uniform a DMA needs (source base of the chunk as an SGPR pair, LDS
-//      destination, "is there a chunk kc+3") is computed in the READ part and pinned in SGPRs, and the per-lane source is a
-//      32-bit offset from the tile's first row -- a DMA costs [branch, m0, global_load_lds v, s[..]] in the MFMA stream
-//      instead of ~8-11 instructions (an in-order wave hides only 1-2 issue slots behind a 16-cycle MFMA: the ISA of variant 1
-//      has ~45 non-MFMA instructions in the multiply part of a chunk)
-// Also measured and dropped: DMAs in the read part (before or after the fragment reads: no gain / -9 %), paired DMAs (= 1).
+// Measured and dropped (profiles/r4_c1*, r4_c2*, r4_c4*): DMAs in the read part (before or after the fragment reads: no gain; all
+// of them there: -9 %), paired DMAs (= 1), and a "lean" multiply part whose scalar address preparation is pinned in the read
+// part (slower than 1: what is added to the read part of one wave delays the MFMA issue of its SIMD partner).
+// PRIO (run-time, TANGO_WIDE_PRIO): 0 = s_setprio 1 around the MFMAs of every multiply part, 1 = no priority changes,
+// 2 = static priority for the later-dispatched half (MI355X_MICROARCH.md "Two waves per SIMD" item 4).
 template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool SK, int SCH>
-__global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, const int pp_mode, unsigned long long* __restrict__ trace) {
+__global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, const int pp_mode, unsigned long long* __restrict__ trace, const int prio) {
   constexpr int BM = 256, BN = 320, CB = 64, NST = 4;
   constexpr int ROWS = BM + BN, STAGE = ROWS * CB;
   constexpr int RG = ROWS / 16;                  // 16-row groups (1 KiB) per stage: 36
@@ -158,6 +157,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
   if (trace) t_first = __builtin_amdgcn_s_memrealtime();
 #endif
   if (half) pp_barrier();                               // the stagger
+  if (prio == 2 && half) __builtin_amdgcn_s_setprio(1);
   int st = 0;
   for (int kc = 0; kc < nk; ++kc) {
     const unsigned char* Xs = dsm + st * STAGE;
@@ -168,22 +168,18 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
     for (int a = 0; a < TN; ++a) wf[a] = *(const u32x4*)(Xs + wrow + a * 16 * CB);
 #pragma unroll
     for (int b = 0; b < TM; ++b) xf[b] = *(const u32x4*)(Xs + xrow + b * 16 * CB);
-    // what the multiply part's DMAs need, wave-uniform, pinned HERE (hipcc otherwise sinks these computations between the MFMAs)
-    int more = sgpr_i32(kc + NST - 1 < nk ? 1 : 0);
-    int more5 = sgpr_i32(more && has5 ? 1 : 0);
-    const unsigned char* sa = sgpr_ptr(At + (int64_t)(kc0 + kc + NST - 1) * CB);
-    const unsigned char* sw = sgpr_ptr(Wt + (int64_t)(kc0 + kc + NST - 1) * CB);
-    unsigned ldst = sgpr_u32(lds0 + st3 * STAGE + (unsigned)wave * 1024u);
-    if (SCH == 2) {
-      asm volatile("" : "+s"(more), "+s"(more5), "+s"(sa), "+s"(sw), "+s"(ldst));
-    }
+    const bool more = kc + NST - 1 < nk;               // chunk kc+3 exists
+    const bool more5 = more && has5;
+    const unsigned char* sa = At + (int64_t)(kc0 + kc + NST - 1) * CB;
+    const unsigned char* sw = Wt + (int64_t)(kc0 + kc + NST - 1) * CB;
+    const unsigned ldst = lds0 + st3 * STAGE + (unsigned)wave * 1024u;
     // this wave's DMAs of chunk kc+1 must have landed before the barrier that precedes anyone's read of that chunk;
     // chunk kc+2 (if issued) may stay in flight
     if (kc + 1 < nk) wait_inflight(kc + 2 < nk ? 1 : 0);
     pp_barrier();
     // ---- multiply part ----
     if (SCH == 0 && more) issue_chunk(kc + NST - 1, st3);
-    __builtin_amdgcn_s_setprio(1);
+    if (prio == 0) __builtin_amdgcn_s_setprio(1);
     if (LN) {
       // row statistics from the activation fragments this wave holds anyway (both column halves compute them: 32 VALU
       // instructions per chunk next to 40 MFMAs)
@@ -202,11 +198,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (prio == 0) __builtin_amdgcn_s_setprio(0);
     pp_barrier();
     st = st == NST - 1 ? 0 : st + 1;
   }
   if (!half) pp_barrier();
+  if (prio == 2) __builtin_amdgcn_s_setprio(0);
   __syncthreads();   // every wave is past its last fragment read: the operand stages become the staging area
 #ifdef TANGO_WIDE_TRACE_BUILD
   if (trace) t_loop = __builtin_amdgcn_s_memrealtime();
@@ -287,7 +284,7 @@ static int launch_wide_sch(const GemmParams& p, hipStream_t s) {
   const bool tracing = getenv("TANGO_WIDE_TRACE") != nullptr && p.splitk <= 1;
   if (tracing) TANGO_HIP(hipMalloc((void**)&trace, (size_t)grid * 40));
 #endif
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS, s, p, pp_mode, trace);
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS, s, p, pp_mode, trace, tuning().wide_prio);
   TANGO_HIP(hipGetLastError());
 #ifdef TANGO_WIDE_TRACE_BUILD
   if (tracing) {
@@ -315,8 +312,7 @@ template <typename T, bool GEGLU, bool RES, bool LN, bool VT = false, bool SK = 
 static int launch_wide_cfg(const GemmParams& p, hipStream_t s) {
   switch (tuning().wide_sched) {
     case 0: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 0>(p, s);
-    case 1: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 1>(p, s);
-    default: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 2>(p, s);
+    default: return launch_wide_sch<T, GEGLU, RES, LN, VT, SK, 1>(p, s);
   }
 }
 

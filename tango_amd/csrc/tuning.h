@@ -22,7 +22,8 @@ struct Tuning {
   bool no_small_tile;       // TANGO_NO_SMALL_TILE=1    A/B: 64 x 64 tiles for small-M linears out (back to split-K + reduce / the streaming kernel) (round 3)
   bool no_xattn_fused;      // TANGO_NO_XATTN_FUSED=1   A/B: fused cross-attention block kernel out (round 3)
   bool no_single_key;       // TANGO_NO_SINGLE_KEY=1    A/B: single-key (unconditional-row) cross-attention shortcut out (round 4)
-  int wide_sched;           // TANGO_WIDE_SCHED=0..2    A/B: where the 256 x 320 kernels issue their LDS-DMAs (gemm_wide.hip: SCH; default 2) (round 4)
+  int wide_prio;            // TANGO_WIDE_PRIO=0..2     A/B: wave priorities in those kernels' ping-pong loops (gemm_wide.hip: PRIO; default 0) (round 4)
+  int wide_sched;           // TANGO_WIDE_SCHED=0..1    A/B: where the 256 x 320 kernels issue their LDS-DMAs (gemm_wide.hip: SCH; default 1) (round 4)
 };
 
 inline Tuning read_tuning() {
@@ -38,7 +39,9 @@ inline Tuning read_tuning() {
   x.no_xattn_fused = on("TANGO_NO_XATTN_FUSED");
   x.no_single_key = on("TANGO_NO_SINGLE_KEY");
   const char* ws = getenv("TANGO_WIDE_SCHED");
-  x.wide_sched = (ws && ws[0] >= '0' && ws[0] <= '2') ? ws[0] - '0' : 2;
+  x.wide_sched = (ws && ws[0] >= '0' && ws[0] <= '1') ? ws[0] - '0' : 1;
+  const char* wp = getenv("TANGO_WIDE_PRIO");
+  x.wide_prio = (wp && wp[0] >= '0' && wp[0] <= '2') ? wp[0] - '0' : 0;
   return x;
 }
 
