@@ -198,6 +198,13 @@ int tango_engine_last_denoise_ms(tango_engine_t* h, float* total_ms, float* per_
 
 /* diagnostic: eager run of one UNet step with HIP events around every kernel group; writes
  * "label<TAB>ms<TAB>GFLOP" lines into `report` (truncated to report_cap). */
+/* Plan cache.  The engine keeps one workspace slab + launch program ("plan") per call shape: UNet (batch, text / beat / chord
+ * lengths, single-key prefix), VAE / vocoder (batch, frames), text encoder (batch, length), STFT (batch, samples).  All of them
+ * share one byte budget (default 64 GiB, or TANGO_PLAN_BUDGET_MB); when a new plan does not fit, least recently used plans are
+ * freed first (hipFree: synchronises the device).  The reference has no counterpart: tango.py:51-64 just re-runs PyTorch eagerly. */
+int tango_engine_set_plan_budget(tango_engine_t* h, uint64_t bytes);
+int tango_engine_plan_stats(tango_engine_t* h, uint64_t* bytes_in_use, int* plans);
+
 int tango_engine_profile_unet(tango_engine_t* h, int batch2, int text_len, char* report, int report_cap, void* stream);
 /* measurement tools only: re-read the TANGO_* dispatch switches (csrc/tuning.h) from the environment, so that one process can
  * time several arms of an A/B back to back (tools/profile_unet_ops.py --ab).  No reference counterpart. */

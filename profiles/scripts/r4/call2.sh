@@ -13,5 +13,5 @@ timeout 500 python tools/profile_unet_ops.py --ab "TANGO_WIDE_SCHED=0;TANGO_WIDE
 timeout 300 python tools/profile_unet_ops.py --batch 8 --ab "TANGO_WIDE_SCHED=0;TANGO_WIDE_SCHED=1" --rounds 3 \
   --grep "conv3x3|linear" --out $O/ab_sched_b8.txt > /dev/null 2>> $O/ab_err.log; echo "ab8 rc=$?"; head -8 $O/ab_sched_b8.txt
 timeout 400 python bench.py --denoise-steps 20 --no-cpu-baseline --no-other-configs > $O/bench_b32_20step.json 2> $O/bench_err.log; echo "bench rc=$?"; cut -c1-400 $O/bench_b32_20step.json
-PMC_OUT=r4c2/pmc_l0 bash tools/r4/pmc.sh run conv_wide_l0_sch1 conv3x3_wide conv 64 320 256 16 320 3 > $O/pmc_l0.log 2>&1; tail -3 $O/pmc_l0.log
-PMC_OUT=r4c2/pmc_l1 bash tools/r4/pmc.sh run conv_wide_l1_sch1 conv3x3_wide conv 64 640 128 8 640 3 > $O/pmc_l1.log 2>&1; tail -3 $O/pmc_l1.log
+PMC_OUT=r4c2/pmc_l0 bash tools/pmc_op.sh run conv_wide_l0_sch1 conv3x3_wide conv 64 320 256 16 320 3 > $O/pmc_l0.log 2>&1; tail -3 $O/pmc_l0.log
+PMC_OUT=r4c2/pmc_l1 bash tools/pmc_op.sh run conv_wide_l1_sch1 conv3x3_wide conv 64 640 128 8 640 3 > $O/pmc_l1.log 2>&1; tail -3 $O/pmc_l1.log

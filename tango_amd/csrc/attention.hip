@@ -391,6 +391,8 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
     TANGO_FAIL("attention: ld alignment");
   const bool masked = p.bias != nullptr || (p.Skv % 64) != 0;
   if (p.fp8_pv && sizeof(T) != 2) TANGO_FAIL("attention: fp8 P.V needs a 16-bit engine (Q.K^T stays in the engine dtype)");
+  //  never fall back silently: a config-5 run must not measure the 16-bit kernel under the fp8 label
+  if (p.fp8_pv && (masked || p.pos_bias)) TANGO_FAIL("attention: fp8 P.V is implemented for unmasked sites with Skv % 64 == 0 only");
   if (p.pos_bias) {   // text-encoder self-attention (short sequences): one query block per wave
     dim3 grid((unsigned)((p.Sq + 63) / 64), (unsigned)p.heads, (unsigned)p.B);
     hipLaunchKernelGGL((attn_kernel<T, 1, true, 4, 3, true>), grid, dim3(256), 0, s, p);

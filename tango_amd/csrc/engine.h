@@ -112,7 +112,16 @@ struct Slot {
   std::function<int(const float*, hipStream_t)> pack;
 };
 
+// every plan (a workspace slab + its launch program, keyed by the call's shape) carries its size and a last-use stamp: the plan
+// caches of an engine share ONE byte budget, least recently used plans are freed first (Engine::make_room; round 4 -- callers of
+// tango.py:51-64 with ragged last batches and mixed prompt lengths used to accumulate ~0.44 GB per prompt without bound)
+struct PlanMeta {
+  size_t bytes = 0;
+  uint64_t stamp = 0;
+};
+
 struct UNetPlan {
+  PlanMeta meta;
   int B2 = 0, L = 0;
   int Lc[3] = {0, 0, 0};    // condition lengths: [0] text (== L), [1] beat, [2] chord (Music UNet only)
   char* slab = nullptr;
@@ -135,6 +144,7 @@ struct T5LayerW {          // T5Block of the encoder: self-attention + gated-GEL
   WMat qkv, o, wi, wo;     // qkv = fused [q; k; v] rows; wi = [wi_1 | wi_0] in the GLU interleave (value | gate)
 };
 struct T5Plan {
+  PlanMeta meta;
   int B = 0, L = 0;
   char* slab = nullptr;
   Program prog;
@@ -145,6 +155,7 @@ struct T5Plan {
   float* out = nullptr;     // [B*L][d_model] fp32
 };
 struct VaePlan {           // also used for the vocoder: plan-owned in/out staging buffers
+  PlanMeta meta;
   int B = 0;
   char* slab = nullptr;
   Program prog;
@@ -155,6 +166,7 @@ struct VaePlan {           // also used for the vocoder: plan-owned in/out stagi
 };
 
 struct StftPlan {          // wave -> log-mel front-end buffers for one (batch, n_samples)
+  PlanMeta meta;
   int B = 0, N = 0, T = 0, Np = 0, Kp2 = 0, ldz = 0;
   char* slab = nullptr;
   float *in = nullptr, *xpad = nullptr, *Z = nullptr, *mag = nullptr, *mel_lin = nullptr, *mel = nullptr, *logmag = nullptr, *energy = nullptr;
@@ -179,6 +191,10 @@ class Engine {
   int mel_spectrogram(const float* wav, float* mel, float* logmag, float* energy, int B, int N, int* n_frames, hipStream_t s);
   int last_denoise_ms(float* total_ms, float* per_step_ms);
   int profile_unet(int B2, int L, std::string& report, hipStream_t s);
+  // plan-cache budget (bytes of workspace slabs kept alive; default 64 GiB or TANGO_PLAN_BUDGET_MB) and its current use
+  void set_plan_budget(size_t bytes) { plan_budget = bytes; }
+  size_t plan_bytes_in_use() const { return plan_bytes; }
+  int plan_count() const;
 
   tango_config_t cfg;
   int dt = DT_F32;
@@ -281,6 +297,13 @@ class Engine {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t cap_stream = nullptr;
   int last_steps = 0;
+
+  // ---- plan caches: shared LRU byte budget ----
+  size_t plan_budget = (size_t)64 << 30, plan_bytes = 0;
+  uint64_t plan_clock = 0;
+  void touch(PlanMeta& m) { m.stamp = ++plan_clock; }
+  int make_room(size_t need);             // frees least-recently-used plans until plan_bytes + need <= plan_budget (or nothing is left)
+  int alloc_slab(char** slab, size_t bytes, PlanMeta& m, bool zero);
 
   int ensure_temb(const int64_t* ts_host, int n, hipStream_t s);
   int get_unet_plan(int B2, int L, int Lbeat, int Lchord, int n_short, UNetPlan** out);

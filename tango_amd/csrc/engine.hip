@@ -347,6 +347,69 @@ void* Engine::dmalloc(size_t bytes) {
   return p;
 }
 
+// ---- plan caches: one byte budget, least recently used first ------------------------------------------------------------------
+namespace {
+template <typename Map> void lru_candidate(Map& m, uint64_t& best, int which, int& best_which) {
+  for (auto& kv : m)
+    if (kv.second->meta.stamp < best) { best = kv.second->meta.stamp; best_which = which; }
+}
+template <typename Map, typename Free> bool lru_erase(Map& m, uint64_t stamp, Free&& fr) {
+  for (auto it = m.begin(); it != m.end(); ++it)
+    if (it->second->meta.stamp == stamp) { fr(*it->second); m.erase(it); return true; }
+  return false;
+}
+}  // namespace
+
+int Engine::plan_count() const {
+  return (int)(unet_plans.size() + vae_plans.size() + vae_enc_plans.size() + voc_plans.size() + t5_plans.size() + stft_plans.size());
+}
+
+int Engine::make_room(size_t need) {
+  while (plan_bytes + need > plan_budget) {
+    uint64_t best = ~0ull;
+    int which = -1;
+    lru_candidate(unet_plans, best, 0, which);
+    lru_candidate(vae_plans, best, 1, which);
+    lru_candidate(vae_enc_plans, best, 2, which);
+    lru_candidate(voc_plans, best, 3, which);
+    lru_candidate(t5_plans, best, 4, which);
+    lru_candidate(stft_plans, best, 5, which);
+    if (which < 0) break;                                   // nothing left to free: let the allocation decide
+    // a slab may still be read by work queued on a stream: hipFree synchronises the device before it releases memory
+    auto drop = [&](auto& P) {
+      plan_bytes -= P.meta.bytes < plan_bytes ? P.meta.bytes : plan_bytes;
+      if (P.slab) (void)hipFree(P.slab);
+    };
+    bool ok = false;
+    switch (which) {
+      case 0:
+        ok = lru_erase(unet_plans, best, [&](UNetPlan& P) {
+          if (P.exec) (void)hipGraphExecDestroy(P.exec);
+          if (P.graph) (void)hipGraphDestroy(P.graph);
+          drop(P);
+        });
+        break;
+      case 1: ok = lru_erase(vae_plans, best, [&](VaePlan& P) { drop(P); }); break;
+      case 2: ok = lru_erase(vae_enc_plans, best, [&](VaePlan& P) { drop(P); }); break;
+      case 3: ok = lru_erase(voc_plans, best, [&](VaePlan& P) { drop(P); }); break;
+      case 4: ok = lru_erase(t5_plans, best, [&](T5Plan& P) { drop(P); }); break;
+      default: ok = lru_erase(stft_plans, best, [&](StftPlan& P) { drop(P); }); break;
+    }
+    if (!ok) break;
+  }
+  return 0;
+}
+
+int Engine::alloc_slab(char** slab, size_t bytes, PlanMeta& m, bool zero) {
+  TANGO_TRY(make_room(bytes));
+  TANGO_HIP(hipMalloc((void**)slab, bytes));
+  if (zero) TANGO_HIP(hipMemset(*slab, 0, bytes));
+  m.bytes = bytes;
+  plan_bytes += bytes;
+  touch(m);
+  return 0;
+}
+
 void Engine::reg_slot(const std::string& name, std::vector<int64_t> shape, std::function<int(const float*, hipStream_t)> pack) {
   Slot s;
   s.name = name;
@@ -727,6 +790,10 @@ void Engine::build_voc_weights() {
 int Engine::init() {
   if (dt != DT_F32 && dt != DT_F16 && dt != DT_BF16) TANGO_FAIL("engine: bad dtype");
   TANGO_TRY(gemm_init());
+  if (const char* mb = getenv("TANGO_PLAN_BUDGET_MB")) {
+    const long long v = atoll(mb);
+    if (v > 0) plan_budget = (size_t)v << 20;
+  }
   if (cfg.unet_attn_fp8 && dt == DT_F32) TANGO_FAIL("engine: unet_attn_fp8 needs a 16-bit engine dtype (bf16 / fp16)");
   if (cfg.unet_levels > 0) {
     for (int i = 0; i < cfg.unet_levels; ++i)
@@ -1029,15 +1096,14 @@ int Engine::get_unet_plan(int B2, int L, int Lbeat, int Lchord, int n_short, UNe
   if (n_short < 0 || n_short > B2) TANGO_FAIL("engine: bad single-key prefix");
   const std::array<int, 5> key = {B2, L, Lbeat, Lchord, n_short};
   auto it = unet_plans.find(key);
-  if (it != unet_plans.end()) { *out = it->second.get(); return 0; }
+  if (it != unet_plans.end()) { touch(it->second->meta); *out = it->second.get(); return 0; }
   if (!finalized) TANGO_FAIL("engine: weights not finalized");
   std::unique_ptr<UNetPlan> P(new UNetPlan());
   P->B2 = B2; P->L = L; P->n_short = n_short;
   P->Lc[0] = L; P->Lc[1] = Lbeat; P->Lc[2] = Lchord;
   Arena m;
   TANGO_TRY(build_unet(*P, m, false));
-  TANGO_HIP(hipMalloc((void**)&P->slab, m.peak + 256));
-  TANGO_HIP(hipMemset(P->slab, 0, m.peak + 256));   // V^T pad columns (L not a multiple of 8) must stay zero
+  TANGO_TRY(alloc_slab(&P->slab, m.peak + 256, P->meta, true));   // zero-filled: V^T pad columns (L not a multiple of 8) must stay zero
   Arena a; a.base = P->slab;
   P->pre.ops.clear(); P->step.ops.clear(); P->pre.labels.clear(); P->step.labels.clear(); P->pre.flops.clear(); P->step.flops.clear();
   TANGO_TRY(build_unet(*P, a, true));
@@ -1318,14 +1384,13 @@ int Engine::build_t5(T5Plan& P, Arena& A, bool record) {
 int Engine::get_t5_plan(int B, int L, T5Plan** out) {
   auto key = std::make_pair(B, L);
   auto it = t5_plans.find(key);
-  if (it != t5_plans.end()) { *out = it->second.get(); return 0; }
+  if (it != t5_plans.end()) { touch(it->second->meta); *out = it->second.get(); return 0; }
   if (!finalized) TANGO_FAIL("engine: weights not finalized");
   std::unique_ptr<T5Plan> P(new T5Plan());
   P->B = B; P->L = L;
   Arena m;
   TANGO_TRY(build_t5(*P, m, false));
-  TANGO_HIP(hipMalloc((void**)&P->slab, m.peak + 256));
-  TANGO_HIP(hipMemset(P->slab, 0, m.peak + 256));
+  TANGO_TRY(alloc_slab(&P->slab, m.peak + 256, P->meta, true));
   Arena a; a.base = P->slab;
   P->prog.ops.clear(); P->prog.labels.clear(); P->prog.flops.clear();
   TANGO_TRY(build_t5(*P, a, true));
@@ -1412,13 +1477,13 @@ int Engine::build_vae(VaePlan& P, Arena& A, bool record) {
 
 int Engine::get_vae_plan(int B, VaePlan** out) {
   auto it = vae_plans.find(B);
-  if (it != vae_plans.end()) { *out = it->second.get(); return 0; }
+  if (it != vae_plans.end()) { touch(it->second->meta); *out = it->second.get(); return 0; }
   if (!finalized) TANGO_FAIL("engine: weights not finalized");
   std::unique_ptr<VaePlan> P(new VaePlan());
   P->B = B;
   Arena m;
   TANGO_TRY(build_vae(*P, m, false));
-  TANGO_HIP(hipMalloc((void**)&P->slab, m.peak + 256));
+  TANGO_TRY(alloc_slab(&P->slab, m.peak + 256, P->meta, false));
   Arena a; a.base = P->slab;
   P->prog.ops.clear();
   TANGO_TRY(build_vae(*P, a, true));
@@ -1504,13 +1569,13 @@ int Engine::build_vae_enc(VaePlan& P, Arena& A, bool record) {
 
 int Engine::get_vae_enc_plan(int B, VaePlan** out) {
   auto it = vae_enc_plans.find(B);
-  if (it != vae_enc_plans.end()) { *out = it->second.get(); return 0; }
+  if (it != vae_enc_plans.end()) { touch(it->second->meta); *out = it->second.get(); return 0; }
   if (!finalized) TANGO_FAIL("engine: weights not finalized");
   std::unique_ptr<VaePlan> P(new VaePlan());
   P->B = B;
   Arena m;
   TANGO_TRY(build_vae_enc(*P, m, false));
-  TANGO_HIP(hipMalloc((void**)&P->slab, m.peak + 256));
+  TANGO_TRY(alloc_slab(&P->slab, m.peak + 256, P->meta, false));
   Arena a; a.base = P->slab;
   P->prog.ops.clear();
   TANGO_TRY(build_vae_enc(*P, a, true));
@@ -1631,13 +1696,13 @@ int Engine::build_voc(VaePlan& P, Arena& A, bool record, int frames) {
 int Engine::get_voc_plan(int B, int frames, VaePlan** out) {
   auto key = std::make_pair(B, frames);
   auto it = voc_plans.find(key);
-  if (it != voc_plans.end()) { *out = it->second.get(); return 0; }
+  if (it != voc_plans.end()) { touch(it->second->meta); *out = it->second.get(); return 0; }
   if (!finalized) TANGO_FAIL("engine: weights not finalized");
   std::unique_ptr<VaePlan> P(new VaePlan());
   P->B = B;
   Arena m;
   TANGO_TRY(build_voc(*P, m, false, frames));
-  TANGO_HIP(hipMalloc((void**)&P->slab, m.peak + 256));
+  TANGO_TRY(alloc_slab(&P->slab, m.peak + 256, P->meta, false));
   Arena a; a.base = P->slab;
   P->prog.ops.clear();
   TANGO_TRY(build_voc(*P, a, true, frames));
@@ -1669,6 +1734,18 @@ extern "C" {
 const char* tango_last_error(void) { return tango::last_error(); }
 const char* tango_version(void) { return "tango-mi355x 0.1 (gfx950)"; }
 void tango_tuning_reload(void) { tango::tuning_reload(); }
+
+int tango_engine_set_plan_budget(tango_engine_t* h, uint64_t bytes) {
+  if (!h) { tango::set_error("tango_engine_set_plan_budget: null engine"); return -1; }
+  h->e->set_plan_budget((size_t)bytes);
+  return 0;
+}
+int tango_engine_plan_stats(tango_engine_t* h, uint64_t* bytes_in_use, int* plans) {
+  if (!h) { tango::set_error("tango_engine_plan_stats: null engine"); return -1; }
+  if (bytes_in_use) *bytes_in_use = (uint64_t)h->e->plan_bytes_in_use();
+  if (plans) *plans = h->e->plan_count();
+  return 0;
+}
 
 int tango_engine_create(const tango_config_t* cfg, tango_engine_t** out) {
   if (!cfg || !out) { tango::set_error("tango_engine_create: null argument"); return -1; }

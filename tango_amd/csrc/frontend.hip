@@ -100,7 +100,7 @@ void Engine::build_stft_weights() {
 int Engine::get_stft_plan(int B, int N, StftPlan** out) {
   auto key = std::make_pair(B, N);
   auto it = stft_plans.find(key);
-  if (it != stft_plans.end()) { *out = it->second.get(); return 0; }
+  if (it != stft_plans.end()) { touch(it->second->meta); *out = it->second.get(); return 0; }
   if (!finalized) TANGO_FAIL("engine: weights not finalized");
   const int nfft = cfg.stft_filter_length, hop = cfg.stft_hop_length, cutoff = nfft / 2 + 1, nmel = cfg.stft_n_mel;
   const int P = nfft / 2;
@@ -123,7 +123,7 @@ int Engine::get_stft_plan(int B, int N, StftPlan** out) {
     S.energy = (float*)A.alloc((size_t)B * S.T * 4);
   };
   carve(a);
-  TANGO_HIP(hipMalloc((void**)&S.slab, a.peak + 256));
+  TANGO_TRY(alloc_slab(&S.slab, a.peak + 256, S.meta, false));
   Arena r; r.base = S.slab;
   carve(r);
   *out = Pn.get();

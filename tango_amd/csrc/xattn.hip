@@ -28,7 +28,11 @@
 // 40-fragment streams 54 us, the epilogue 58 us (HBM: it re-read the residual then), prologue + softmax chain ~100 us, DMA waits
 // and barriers ~30 us -- with one workgroup per CU (156 KiB of LDS) the HBM phases and the MFMA phases of a tile do not overlap.
 //
-// Constraints (else the engine keeps the three-launch path): 16-bit engine, C = 320 (5 heads), 64 text tokens, HW % 128 == 0.
+// Constraints (else the engine keeps the three-launch path): 16-bit engine, C = 320 (5 heads), 1 <= L <= 64 text tokens, HW % 128 == 0.
+// Round 4: L < 64 (the reference pads to the longest prompt of the batch, models.py:131-133; the shim buckets to 16 / 32 / 64 / 128)
+// runs the same 64-key kernel: key slots >= L carry the -1e30 bias this kernel already gives them (exp2 -> exactly 0), their K rows
+// are read from the sample's last real key and their V^T pieces from the row's first piece (finite values, weight 0): no read
+// leaves the sample's K / V^T block.
 #include "common.h"
 #include "gemm_device.h"
 #include "tuning.h"
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(512) void xattn_block_kernel(const XAttnParams p) {
   const unsigned char* const Xb = (const unsigned char*)p.x;
   const unsigned char* const Wq = (const unsigned char*)p.wq;
   const unsigned char* const Wo = (const unsigned char*)p.wo;
-  const unsigned char* const Kb = (const unsigned char*)p.k + (int64_t)b * XA_L * p.ldk * 2;
+  const unsigned char* const Kb = (const unsigned char*)p.k + (int64_t)b * p.L * p.ldk * 2;
   const unsigned char* const Vb = (const unsigned char*)p.vt + (int64_t)b * XA_C * p.ldvt * 2;
   float* const cst = (float*)(dsm + XA_OFF_CST);
 
@@ -150,8 +154,11 @@ __global__ __launch_bounds__(512) void xattn_block_kernel(const XAttnParams p) {
     for (int i = 0; i < 2; ++i) {
       const int e = 2 * wave + i, isv = e >> 3, c = (e >> 2) & 1, rg = e & 3;
       const int nat = xa_perm(rg * 16 + lrow);
-      const unsigned char* src = isv ? Vb + ((int64_t)(h * 64 + nat) * p.ldvt + c * 32) * 2 + dpc
-                                     : Kb + ((int64_t)nat * p.ldk + h * 64 + c * 32) * 2 + dpc;
+      // L < 64: key slots >= L are masked by their bias; keep their reads inside the sample (last real key / first V^T piece)
+      const int key = nat < p.L ? nat : p.L - 1;
+      const int vkey0 = c * 32 + (dpc >> 1);                          // first of the 8 keys this lane's 16-byte V^T piece holds
+      const unsigned char* src = isv ? Vb + (int64_t)(h * 64 + nat) * p.ldvt * 2 + (vkey0 < p.ldvt ? (c * 32) * 2 + dpc : 0)
+                                     : Kb + ((int64_t)key * p.ldk + h * 64 + c * 32) * 2 + dpc;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dsm + XA_OFF_KV + buf * XA_KV + isv * (2 * 64 * CB) + c * (64 * CB) + rg * 1024), 16, 0, 0);
     }
   };
@@ -367,7 +374,7 @@ int launch_xattn_permute_wq(int dtype, const void* W, const float* b, const floa
 
 bool xattn_block_ok(int dtype, int C, int heads, int HW, int L, int64_t ldx, int64_t ldo, int64_t ldk, int64_t ldvt) {
   if (tuning().no_xattn_fused || dtype == DT_F32) return false;
-  if (C != XA_C || heads != XA_HEADS || L != XA_L || HW % XA_ROWS != 0) return false;
+  if (C != XA_C || heads != XA_HEADS || L < 1 || L > XA_L || HW % XA_ROWS != 0) return false;
   return ldx % 8 == 0 && ldo % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0;
 }
 

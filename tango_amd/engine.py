@@ -237,7 +237,8 @@ class Engine:
         out = torch.empty_like(x)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
         music = bool(self.unet_cfg.get("music"))
-        if music != (beat_features is not None and chord_features is not None):
+        given = (beat_features is not None, chord_features is not None)
+        if (music and not all(given)) or (not music and any(given)):
             raise ValueError("beat_features / chord_features are required by (and only by) a Music UNet config")
         with torch.cuda.device(self.device):
             if music:
@@ -314,6 +315,16 @@ class Engine:
             lab, ms, gf = line.rsplit("\t", 2)
             rows.append((lab, float(ms), float(gf)))
         return rows
+
+    def set_plan_budget(self, nbytes: int):
+        """byte budget of the plan cache (workspace slabs kept alive per call shape); least recently used plans are freed first"""
+        _lib.check(self.lib.tango_engine_set_plan_budget(self._h, int(nbytes)), "set_plan_budget")
+
+    def plan_stats(self):
+        """(bytes of plan workspace alive, number of cached plans)"""
+        b, n = C.c_uint64(), C.c_int()
+        _lib.check(self.lib.tango_engine_plan_stats(self._h, C.byref(b), C.byref(n)), "plan_stats")
+        return int(b.value), int(n.value)
 
     def last_denoise_ms(self):
         tot, per = C.c_float(), C.c_float()

@@ -202,10 +202,10 @@ class AudioDiffusion:
         pm[:, :L] = mask
         return pe, pm
 
-    @torch.no_grad()
-    def inference_from_embeddings(self, prompt_embeds, boolean_prompt_mask, inference_scheduler, num_steps=20,
-                                  guidance_scale=3, latents=None, noise=None, seed=None, sample_offset=0):
-        """Loop of models.py:224-249 given the encoder outputs ([uncond; cond] when guidance > 1)."""
+    def _denoise(self, prompt_embeds, boolean_prompt_mask, inference_scheduler, num_steps, guidance_scale, latents, noise, seed,
+                 sample_offset, **extra_conditions):
+        """the shared body of the loop of models.py:224-249 / mustango/models.py:563-598: seed derivation, text bucketing, scheduler
+        tables, one engine call (`extra_conditions`: the Music UNet's beat / chord streams)"""
         cfg_on = guidance_scale > 1.0
         B = prompt_embeds.shape[0] // 2 if cfg_on else prompt_embeds.shape[0]
         inference_scheduler.set_timesteps(num_steps, device=self.device)
@@ -225,8 +225,15 @@ class AudioDiffusion:
         self.engine.denoise(latents, pe, pm, timesteps.cpu().numpy(), inference_scheduler.coef_table(), guidance_scale,
                             prediction_type=c.prediction_type, rule=inference_scheduler.rule, clip_sample=c.clip_sample,
                             clip_sample_range=getattr(c, "clip_sample_range", 1.0), noise=noise, seed=seed,
-                            sample_offset=sample_offset, use_graph=self.use_graph)
+                            sample_offset=sample_offset, use_graph=self.use_graph, **extra_conditions)
         return latents
+
+    @torch.no_grad()
+    def inference_from_embeddings(self, prompt_embeds, boolean_prompt_mask, inference_scheduler, num_steps=20,
+                                  guidance_scale=3, latents=None, noise=None, seed=None, sample_offset=0):
+        """Loop of models.py:224-249 given the encoder outputs ([uncond; cond] when guidance > 1)."""
+        return self._denoise(prompt_embeds, boolean_prompt_mask, inference_scheduler, num_steps, guidance_scale, latents, noise, seed,
+                             sample_offset)
 
     @torch.no_grad()
     def inference(self, prompt, inference_scheduler, num_steps=20, guidance_scale=3, num_samples_per_prompt=1,
@@ -265,25 +272,9 @@ class MusicAudioDiffusion(AudioDiffusion):
         """mustango/models.py:540-598 given the three encoder outputs ([uncond; cond] when guidance > 1)."""
         if encoded_beats is None or encoded_chords is None:
             raise ValueError("encoded_beats and encoded_chords are required (mustango/models.py:548-550)")
-        cfg_on = guidance_scale > 1.0
-        B = prompt_embeds.shape[0] // 2 if cfg_on else prompt_embeds.shape[0]
-        inference_scheduler.set_timesteps(num_steps, device=self.device)
-        if latents is None:
-            latents = self.prepare_latents(B, inference_scheduler, self.unet.config.in_channels, torch.float32, self.device)
-        latents = latents.to(self.device, torch.float32).contiguous().clone()
-        if boolean_prompt_mask is None:
-            boolean_prompt_mask = torch.ones(prompt_embeds.shape[:2], dtype=torch.bool, device=prompt_embeds.device)
-        pe, pm = self._pad_text(prompt_embeds.to(self.device), boolean_prompt_mask.to(self.device))
-        c = inference_scheduler.config
-        if seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.seed is None else (int(self.seed) << 20) + self._calls
-        self._calls += 1
-        self.engine.denoise(latents, pe, pm, inference_scheduler.timesteps.cpu().numpy(), inference_scheduler.coef_table(), guidance_scale,
-                            prediction_type=c.prediction_type, rule=inference_scheduler.rule, clip_sample=c.clip_sample,
-                            clip_sample_range=getattr(c, "clip_sample_range", 1.0), noise=noise, seed=seed,
-                            sample_offset=sample_offset, use_graph=self.use_graph, beat_embeds=encoded_beats, beat_mask=beat_mask,
-                            chord_embeds=encoded_chords, chord_mask=chord_mask)
-        return latents
+        return self._denoise(prompt_embeds, boolean_prompt_mask, inference_scheduler, num_steps, guidance_scale, latents, noise, seed,
+                             sample_offset, beat_embeds=encoded_beats, beat_mask=beat_mask, chord_embeds=encoded_chords,
+                             chord_mask=chord_mask)
 
     def inference(self, *a, **k):
         raise NotImplementedError("strings / beat and chord annotations are encoded by the caller's Mustango front-end modules; "

@@ -134,7 +134,12 @@ class DDIMScheduler(_SchedulerBase):
     def set_timesteps(self, num_inference_steps, device=None):
         self.timesteps = torch.from_numpy(self._base_timesteps(num_inference_steps)) + self.config.steps_offset
 
-    def coef_table(self) -> np.ndarray:
+    def coef_table(self, eta=None) -> np.ndarray:
+        """per-step coefficients of the fused update; `eta` overrides the constructor's value for this table (the fork passes eta to
+        every step() call, scheduling_ddim.py:238: here the loop is one engine call, so it is a per-table argument)"""
+        eta = self.eta if eta is None else float(eta)
+        if eta < 0:
+            raise ValueError("eta must be >= 0")
         rows = []
         T = self.config.num_train_timesteps
         for t in self.timesteps.tolist():
@@ -143,7 +148,7 @@ class DDIMScheduler(_SchedulerBase):
             a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
             b_t = 1 - a_t
             var = ((1 - a_prev) / (1 - a_t)) * (1 - a_t / a_prev)          # scheduling_ddim.py:184-193
-            std = self.eta * var ** 0.5                                      # :316-317 (eta = 0 -> std_dev_t = 0)
+            std = eta * var ** 0.5                                           # :316-317 (eta = 0 -> std_dev_t = 0)
             direction = (1 - a_prev - std ** 2) ** 0.5                       # :340
             rows.append([float(a_t ** 0.5), float(b_t ** 0.5), 0.0, 0.0, float(std), float(a_prev ** 0.5), float(direction), 0.0])
         return np.asarray(rows, dtype=np.float32)

@@ -70,8 +70,6 @@ class _StftFn:
 
 
 class TacotronSTFT:
-    MAX_PLANS = 16          # distinct (batch, n_samples) workspaces kept alive at a time
-
     def __init__(self, filter_length, hop_length, win_length, n_mel_channels, sampling_rate, mel_fmin, mel_fmax, *, device="cuda:0"):
         self.n_mel_channels = n_mel_channels
         self.sampling_rate = sampling_rate
@@ -80,8 +78,6 @@ class TacotronSTFT:
         self.device = torch.device(device)
         self.mel_basis = torch.from_numpy(slaney_mel_filterbank(sampling_rate, filter_length, n_mel_channels, mel_fmin, mel_fmax))
         self.stft_fn = _StftFn(filter_length, hop_length, win_length, stft_forward_basis(filter_length, win_length))
-        self._device_arg = device
-        self._shapes = set()
         self.engine = Engine(stft=self.config, dtype="fp32", device=device)      # raises without the HIP library / a GPU
         self._push()
 
@@ -128,16 +124,7 @@ class TacotronSTFT:
             raise NotImplementedError("the engine implements the reference's default normalize_fun=torch.log")
         assert torch.min(y.data) >= -1, torch.min(y.data)           # the reference's own input checks (stft.py:176-177)
         assert torch.max(y.data) <= 1, torch.max(y.data)
-        # The engine keeps one plan (workspace slab) per (batch, n_samples).  A data-preparation loop over clips of arbitrary
-        # lengths would accumulate them without bound, so after MAX_PLANS distinct shapes the engine handle is rebuilt (two
-        # small weight uploads), which frees every slab.
-        key = (int(y.shape[0]), int(y.shape[-1]))
-        if key not in self._shapes:
-            if len(self._shapes) >= self.MAX_PLANS:
-                self.engine = Engine(stft=self.config, dtype="fp32", device=self._device_arg)
-                self._push()
-                self._shapes.clear()
-            self._shapes.add(key)
+        # (one plan -- workspace slab -- per (batch, n_samples); the engine's LRU byte budget frees old ones: Engine.set_plan_budget)
         return self.engine.mel_spectrogram(y)
 
 

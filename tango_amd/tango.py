@@ -108,7 +108,8 @@ class Tango:
             # torch.manual_seed must not start their samples from identical noise, and the result must not depend on the
             # number of ranks (parallel.py docstring)
             b = pe.shape[0] // 2 if guidance > 1.0 else pe.shape[0]
-            lat = dp_initial_latents(seed, offset, b, self.model.unet.config.in_channels) * self.scheduler.init_noise_sigma
+            ecfg = self.model.engine._cfg
+            lat = dp_initial_latents(seed, offset, b, self.model.unet.config.in_channels, ecfg.latent_h, ecfg.latent_w) * self.scheduler.init_noise_sigma
             latents = self.model.inference_from_embeddings(pe, pm, self.scheduler, steps, guidance, latents=lat, seed=seed,
                                                            sample_offset=offset)
             return self.vae.engine.vocode(self.vae.decode_first_stage(latents))      # int16 stays on the device
@@ -125,14 +126,17 @@ class Tango:
             return self.vae.decode_to_waveform(mel)
 
 
-def dp_initial_latents(seed, offset, count, channels=8):
-    """Initial latents [count, channels, 256, 16] (fp32, CPU) of the samples with GLOBAL indices offset .. offset+count-1 under
-    the pass seed: one torch generator per sample, so a shard of a batch draws exactly what the unsharded batch would."""
+def dp_initial_latents(seed, offset, count, channels=8, height=256, width=16):
+    """Initial latents [count, channels, height, width] (fp32, CPU; the engine's latent size) of the samples with GLOBAL indices
+    offset .. offset+count-1 under the pass seed: one torch generator per sample, so a shard of a batch draws exactly what the
+    unsharded batch would.  NOT the draw of `prepare_latents` (models.py:259-264: one randn of the whole batch from torch's global
+    generator): `generate_for_batch_dp` at world size 1 and `generate_for_batch` under the same torch.manual_seed give different
+    (equally distributed) samples -- the price of results that do not depend on the number of ranks."""
     out = []
     for i in range(count):
         g = torch.Generator(device="cpu").manual_seed((int(seed) * 1000003 + offset + i) % (2 ** 63 - 1))
-        out.append(torch.randn(channels, 256, 16, generator=g))
-    return torch.stack(out) if out else torch.zeros(0, channels, 256, 16)
+        out.append(torch.randn(channels, height, width, generator=g))
+    return torch.stack(out) if out else torch.zeros(0, channels, height, width)
 
 
 def _ddpm_keys(cfg):

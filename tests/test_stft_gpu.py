@@ -93,16 +93,20 @@ def test_state_dict_and_errors():
     _compare(m.cpu(), m0, "n_fft 512 / hop 128 / win 400 / 40 mels")
 
 
-def test_plan_cache_is_bounded_over_arbitrary_clip_lengths(monkeypatch):
-    """a data-preparation loop over clips of many different lengths: the front-end keeps at most MAX_PLANS workspaces alive (the engine
-    handle is rebuilt when the bound is hit) and results do not depend on where in that cycle a clip falls"""
-    monkeypatch.setattr(TacotronSTFT, "MAX_PLANS", 2)
+def test_plan_cache_is_bounded_over_arbitrary_clip_lengths():
+    """a data-preparation loop over clips of many different lengths: the engine's plan cache stays inside its byte budget (least
+    recently used workspaces are freed inside the engine, round 4) and results do not depend on where in that cycle a clip falls"""
     stft = TacotronSTFT(**S.AUDIOLDM_STFT_CONFIG)
-    first_engine = stft.engine
-    for i, N in enumerate([4000, 4160, 5000, 4000, 7777]):
+    stft.mel_spectrogram(stft_wave(B=1, N=4000, seed=1).cuda())
+    one, n = stft.engine.plan_stats()
+    assert n == 1 and one > 0
+    budget = int(2.5 * one)                      # room for two clips of about this length
+    stft.engine.set_plan_budget(budget)
+    for i, N in enumerate([4000, 4160, 5000, 4000, 7777, 4160]):
         y = stft_wave(B=1, N=N, seed=N)
         mel, _, _ = stft.mel_spectrogram(y.cuda())
         m0, _, _ = S.mel_spectrogram(y, stft.mel_basis, stft.stft_fn.forward_basis)
         _compare(mel.cpu(), m0, "clip %d (N=%d)" % (i, N))
-        assert len(stft._shapes) <= 2
-    assert stft.engine is not first_engine
+        used, n = stft.engine.plan_stats()
+        assert n >= 1 and (used <= budget or n == 1), (used, budget, n)
+    assert n <= 2
