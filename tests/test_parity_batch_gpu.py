@@ -93,8 +93,8 @@ def _batch(B):
     return enc, mask, x2, d["lat0"][:B].clone(), d["noises"][:, :B].contiguous()
 
 
-# measured (round 3): fp32 3.4e-6 rel / 1.75e-5 abs, fp16 1.2e-3 ... 1.7e-3 rel / 5.1e-3 ... 6.2e-3 abs
-@pytest.mark.parametrize("dtype,fwd_tol,lat_tol", [("fp32", 1e-5, 5e-5), ("fp16", 4.5e-3, 1.8e-2), ("bf16", 3.6e-2, 1.5e-1)])
+# measured (rounds 3-4): fp32 3.5e-6 rel / 1.75e-5 abs, fp16 1.2e-3 ... 1.7e-3 rel / 5.1e-3 ... 6.2e-3 abs, bf16 0.96 ... 1.14e-2 / 4.2 ... 5.0e-2
+@pytest.mark.parametrize("dtype,fwd_tol,lat_tol", [("fp32", 1e-5, 5e-5), ("fp16", 4.5e-3, 1.8e-2), ("bf16", 3.4e-2, 1.5e-1)])
 def test_unet_and_loop_at_benchmarked_batch(dtype, fwd_tol, lat_tol):
     e = _engine(dtype)
     sch = DDPMScheduler.from_config({k: SD21_SCHEDULER_CONFIG[k] for k in _KEYS})
@@ -156,7 +156,7 @@ def test_geglu_projection_config3_size(lib, dtype):
 def test_config5_shard_xl_bf16_fp8_attention_b8():
     """BASELINE config 5's per-GPU shard as it runs: FLAN-T5-XL cross-attention width (2048), bf16 storage, fp8 P.V self-attention,
     B = 8 prompts (UNet batch 16): one forward and the 3-step CFG loop through the hipGraph, rows {0, 3, 7} against the fp32 oracle
-    of the XL config.  Floors: 3x the bf16 values of the LARGE config (the XL width only changes the K/V projections)."""
+    of the XL config.  Measured (round 4): 0.94 ... 1.22e-2 forward, 4.7 ... 5.0e-2 loop; floors 3x."""
     cfg = O.UNET_CONFIG_XL
     sd = W.synth_state_dict(W.unet_param_shapes(cfg, "unet."), 1234)
     B, rows = 8, (0, 3, 7)
@@ -223,7 +223,7 @@ def test_full_size_forward_at_the_other_text_buckets(Lt):
 def test_100_steps_fp16_engine_against_fp32_engine():
     """BASELINE config 2's length (100 DDPM steps, B = 1, guidance 3, device Philox noise identical in both engines) -- the default-suite
     version of tests/test_parity_long_gpu.py: fp16 engine vs the fp32 ENGINE (which the oracle pins at 10 and, opt-in, 100 steps).
-    Measured (round 3, 200 steps): 4.0e-3; floor 3x."""
+    Measured (round 4): 3.3e-3; floor 3x."""
     N = 100
     g = torch.Generator().manual_seed(404)
     enc = torch.cat([torch.randn(1, L, 1024, generator=g), torch.randn(1, L, 1024, generator=g)])
@@ -242,4 +242,4 @@ def test_100_steps_fp16_engine_against_fp32_engine():
         del e
     err = (res["fp16"] - res["fp32"]).abs().max().item()
     print("100 DDPM steps (config 2's length) fp16 engine vs fp32 engine: latents max abs err %.3e (|ref| max %.2f)" % (err, res["fp32"].abs().max()))
-    assert torch.isfinite(res["fp16"]).all() and err <= 1.2e-2
+    assert torch.isfinite(res["fp16"]).all() and err <= 1.0e-2
