@@ -139,6 +139,10 @@ typedef struct tango_denoise_args {
   const float* chord_embeds;
   const uint8_t* chord_mask;
   int32_t chord_len;
+  /* optional HOST copy of prompt_mask (bool [rows, text_len], the tokenizer's attention mask before it was uploaded).  The engine
+   * picks its plan from the mask's structure (the unconditional rows of a CFG batch keep one key, models.py:282-289); with the host
+   * copy it does so without reading the device mask back, i.e. without a host sync on `stream`.  NULL: read-back (one sync). */
+  const uint8_t* prompt_mask_host;
 } tango_denoise_args_t;
 
 const char* tango_last_error(void);

@@ -93,6 +93,7 @@ class DenoiseArgs(C.Structure):
         ("chord_embeds", C.c_void_p),
         ("chord_mask", C.c_void_p),
         ("chord_len", C.c_int32),
+        ("prompt_mask_host", C.c_void_p),
     ]
 
 

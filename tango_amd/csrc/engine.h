@@ -181,7 +181,7 @@ class Engine {
   int set_weight(const char* name, const float* dev, const int64_t* shape, int ndim);
   int finalize_weights();
   int denoise(const tango_denoise_args_t& a, hipStream_t s);
-  struct Cond { const float* emb = nullptr; const uint8_t* mask = nullptr; int len = 0; };
+  struct Cond { const float* emb = nullptr; const uint8_t* mask = nullptr; int len = 0; const uint8_t* mask_host = nullptr; };
   int unet_forward(const float* sample, int64_t t, const Cond (&c)[3], float* out, int B2, hipStream_t s);
   int vae_decode(const float* lat, float* mel, int B, hipStream_t s);
   int vae_encode(const float* mel, float* moments, int B, hipStream_t s);
@@ -298,6 +298,18 @@ class Engine {
   hipStream_t cap_stream = nullptr;
   int last_steps = 0;
 
+  // ---- host -> device staging without a host sync (round 4) ----
+  // Small per-call tables (timesteps, scheduler coefficients, the SchedParams block, single-key indices) come from pageable /
+  // transient host memory.  They are copied into engine-owned PINNED slots and uploaded with hipMemcpyAsync; a slot is reused
+  // only after the event recorded behind its upload has fired, so neither the caller's buffer nor the slot can be overwritten
+  // under a pending copy and `denoise` returns without waiting for the stream.
+  struct HostSlot { void* buf = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
+  static constexpr int kHostSlots = 8;
+  static constexpr size_t kHostSlotBytes = 64 << 10;
+  HostSlot hslots[kHostSlots];
+  int hslot_next = 0;
+  int stage_h2d(void* dst_dev, const void* src_host, size_t bytes, hipStream_t s);
+
   // ---- plan caches: shared LRU byte budget ----
   size_t plan_budget = (size_t)64 << 30, plan_bytes = 0;
   uint64_t plan_clock = 0;
@@ -307,7 +319,7 @@ class Engine {
 
   int ensure_temb(const int64_t* ts_host, int n, hipStream_t s);
   int get_unet_plan(int B2, int L, int Lbeat, int Lchord, int n_short, UNetPlan** out);
-  int single_key_prefix(const uint8_t* mask_dev, int B2, int L, std::vector<int>& key0, hipStream_t s);
+  int single_key_prefix(const uint8_t* mask_dev, const uint8_t* mask_host, int B2, int L, std::vector<int>& key0, hipStream_t s);
   int build_unet(UNetPlan& P, Arena& A, bool record);
   int get_vae_plan(int B, VaePlan** out);
   int build_vae(VaePlan& P, Arena& A, bool record);

@@ -331,6 +331,10 @@ Engine::~Engine() {
   for (auto& kv : t5_plans) if (kv.second->slab) (void)hipFree(kv.second->slab);
   for (auto& kv : stft_plans) if (kv.second->slab) (void)hipFree(kv.second->slab);
   for (void* p : owned) (void)hipFree(p);
+  for (auto& hs : hslots) {
+    if (hs.ev) (void)hipEventDestroy(hs.ev);
+    if (hs.buf) (void)hipHostFree(hs.buf);
+  }
   if (cap_stream) (void)hipStreamDestroy(cap_stream);
   if (ev0) (void)hipEventDestroy(ev0);
   if (ev1) (void)hipEventDestroy(ev1);
@@ -359,6 +363,27 @@ template <typename Map, typename Free> bool lru_erase(Map& m, uint64_t stamp, Fr
   return false;
 }
 }  // namespace
+
+int Engine::stage_h2d(void* dst_dev, const void* src_host, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return 0;
+  if (bytes > kHostSlotBytes) {          // never on the hot path (tables are <= 32 KB): plain synchronous upload
+    TANGO_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s));
+    TANGO_HIP(hipStreamSynchronize(s));
+    return 0;
+  }
+  HostSlot& hs = hslots[hslot_next];
+  hslot_next = (hslot_next + 1) % kHostSlots;
+  if (!hs.buf) {
+    TANGO_HIP(hipHostMalloc(&hs.buf, kHostSlotBytes, hipHostMallocDefault));
+    TANGO_HIP(hipEventCreateWithFlags(&hs.ev, hipEventDisableTiming));
+  }
+  if (hs.pending) TANGO_HIP(hipEventSynchronize(hs.ev));     // the upload that last used this slot (eight stagings ago) has run
+  memcpy(hs.buf, src_host, bytes);
+  TANGO_HIP(hipMemcpyAsync(dst_dev, hs.buf, bytes, hipMemcpyHostToDevice, s));
+  TANGO_HIP(hipEventRecord(hs.ev, s));
+  hs.pending = true;
+  return 0;
+}
 
 int Engine::plan_count() const {
   return (int)(unet_plans.size() + vae_plans.size() + vae_enc_plans.size() + voc_plans.size() + t5_plans.size() + stft_plans.size());
@@ -903,8 +928,7 @@ static GemmParams f32_linear(const float* x, int64_t lda, const WLinF32& w, floa
 int Engine::ensure_temb(const int64_t* ts_host, int n, hipStream_t s) {
   if (n > max_steps) TANGO_FAIL("denoise: num_steps exceeds 1000");
   if ((int)temb_ts.size() == n && std::equal(temb_ts.begin(), temb_ts.end(), ts_host)) return 0;
-  TANGO_HIP(hipMemcpyAsync(d_ts, ts_host, (size_t)n * 8, hipMemcpyHostToDevice, s));
-  TANGO_HIP(hipStreamSynchronize(s));   // ts_host may be pageable / transient
+  TANGO_TRY(stage_h2d(d_ts, ts_host, (size_t)n * 8, s));   // ts_host may be pageable / transient: pinned staging, no host sync
   const int c0 = cfg.unet_channels[0];
   TANGO_TRY(launch_timestep_embedding(d_ts, d_sin, n, c0, cfg.unet_flip_sin_to_cos, cfg.unet_freq_shift, s));
   TANGO_TRY(launch_gemm(DT_F32, f32_linear(d_sin, c0, time1, d_t1, n, ACT_NONE, ACT_SILU), s));
@@ -1116,8 +1140,7 @@ int Engine::bind_text(UNetPlan& P, const Cond (&c)[3], const std::vector<int>& k
   const int ncond = cfg.unet_music ? 3 : 1;
   if (P.n_short > 0) {
     if ((int)key0.size() < P.n_short) TANGO_FAIL("engine: single-key prefix without key indices");
-    TANGO_HIP(hipMemcpyAsync(P.key0, key0.data(), (size_t)P.n_short * 4, hipMemcpyHostToDevice, s));
-    TANGO_HIP(hipStreamSynchronize(s));   // key0 is transient host memory
+    TANGO_TRY(stage_h2d(P.key0, key0.data(), (size_t)P.n_short * 4, s));   // key0 is transient host memory
   }
   for (int i = 0; i < ncond; ++i) {
     if (!c[i].emb) TANGO_FAIL("engine: missing condition embeddings");
@@ -1132,12 +1155,17 @@ int Engine::bind_text(UNetPlan& P, const Cond (&c)[3], const std::vector<int>& k
 // How many leading samples keep exactly ONE text key (and which): the unconditional half of a CFG batch is T5("") = one valid token
 // (models.py:282-289).  One small device -> host copy per call.  Only the two shapes a CFG caller produces get their own plan --
 // the whole batch, or exactly its first half -- so that odd masks cannot multiply the (large) plans.
-int Engine::single_key_prefix(const uint8_t* mask_dev, int B2, int L, std::vector<int>& key0, hipStream_t s) {
+int Engine::single_key_prefix(const uint8_t* mask_dev, const uint8_t* mask_host, int B2, int L, std::vector<int>& key0, hipStream_t s) {
   key0.clear();
-  if (!mask_dev || tuning().no_single_key || B2 <= 0 || L <= 0) return 0;
-  std::vector<uint8_t> m((size_t)B2 * L);
-  if (hipMemcpyAsync(m.data(), mask_dev, m.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return 0;
-  if (hipStreamSynchronize(s) != hipSuccess) return 0;
+  if ((!mask_dev && !mask_host) || tuning().no_single_key || B2 <= 0 || L <= 0) return 0;
+  std::vector<uint8_t> mbuf;
+  const uint8_t* m = mask_host;          // the caller's host copy of the mask (tokenizer output): no read-back, no host sync
+  if (!m) {
+    mbuf.resize((size_t)B2 * L);
+    if (hipMemcpyAsync(mbuf.data(), mask_dev, mbuf.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return 0;
+    if (hipStreamSynchronize(s) != hipSuccess) return 0;
+    m = mbuf.data();
+  }
   for (int b = 0; b < B2; ++b) {
     int cnt = 0, idx = 0;
     for (int j = 0; j < L; ++j) if (m[(size_t)b * L + j]) { ++cnt; idx = j; }
@@ -1153,7 +1181,7 @@ int Engine::single_key_prefix(const uint8_t* mask_dev, int B2, int L, std::vecto
 int Engine::unet_forward(const float* sample, int64_t t, const Cond (&c)[3], float* out, int B2, hipStream_t s) {
   UNetPlan* P;
   std::vector<int> key0;
-  const int ns = single_key_prefix(c[0].mask, B2, c[0].len, key0, s);
+  const int ns = single_key_prefix(c[0].mask, c[0].mask_host, B2, c[0].len, key0, s);
   TANGO_TRY(get_unet_plan(B2, c[0].len, c[1].len, c[2].len, ns, &P));
   TANGO_TRY(ensure_temb(&t, 1, s));
   TANGO_HIP(hipMemsetAsync(d_step, 0, 4, s));
@@ -1172,7 +1200,7 @@ int Engine::denoise(const tango_denoise_args_t& a, hipStream_t s) {
   const int B = a.batch, B2 = cfg_on ? 2 * B : B;
   UNetPlan* P;
   std::vector<int> key0;
-  const int ns = single_key_prefix(a.prompt_mask, B2, a.text_len, key0, s);
+  const int ns = single_key_prefix(a.prompt_mask, a.prompt_mask_host, B2, a.text_len, key0, s);
   TANGO_TRY(get_unet_plan(B2, a.text_len, a.beat_len, a.chord_len, ns, &P));
   TANGO_TRY(ensure_temb(a.timesteps, a.num_steps, s));
   const int HW = cfg.latent_h * cfg.latent_w;
@@ -1185,9 +1213,9 @@ int Engine::denoise(const tango_denoise_args_t& a, hipStream_t s) {
   sp.seed = a.seed; sp.sample_offset = a.sample_offset;
   // per-call tables and the scheduler parameter block live in device memory, so the captured graph of one denoise
   // step (UNet + CFG/scheduler update + step counter) is independent of the call's pointers and scalars
-  TANGO_HIP(hipMemcpyAsync(d_coef, a.coef, (size_t)a.num_steps * 8 * 4, hipMemcpyHostToDevice, s));
-  TANGO_HIP(hipMemcpyAsync(d_sched, &sp, sizeof(SchedParams), hipMemcpyHostToDevice, s));
-  TANGO_HIP(hipStreamSynchronize(s));   // both sources are pageable / transient host memory
+  // (both sources are pageable / transient host memory: pinned staging slots, no host sync -- stage_h2d)
+  TANGO_TRY(stage_h2d(d_coef, a.coef, (size_t)a.num_steps * 8 * 4, s));
+  TANGO_TRY(stage_h2d(d_sched, &sp, sizeof(SchedParams), s));
   TANGO_HIP(hipMemsetAsync(d_step, 0, 4, s));
   {
     Cond c[3];

@@ -263,6 +263,9 @@ class Engine:
         self._check_latents("latents", latents)
         enc = self._f32(prompt_embeds)
         mask = prompt_mask.to(self.device).to(torch.uint8).contiguous() if prompt_mask is not None else None
+        # a mask that is still on the host (tokenizer output) also travels as a host pointer: the engine then picks its plan without
+        # reading the device copy back (no host sync inside the call)
+        mask_host = prompt_mask.to(torch.uint8).contiguous() if prompt_mask is not None and not prompt_mask.is_cuda else None
         rows = 2 * latents.shape[0] if guidance_scale > 1.0 else latents.shape[0]
         self._check_cond("prompt_embeds", enc, mask, rows)
         ts = np.ascontiguousarray(np.asarray(timesteps, dtype=np.int64))
@@ -276,6 +279,7 @@ class Engine:
         a.latents = latents.data_ptr()
         a.prompt_embeds = enc.data_ptr()
         a.prompt_mask = mask.data_ptr() if mask is not None else None
+        a.prompt_mask_host = mask_host.data_ptr() if mask_host is not None else None
         a.batch = latents.shape[0]
         a.text_len = enc.shape[1]
         a.num_steps = len(ts)

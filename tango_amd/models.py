@@ -215,7 +215,8 @@ class AudioDiffusion:
         latents = latents.to(self.device, torch.float32).contiguous().clone()
         if boolean_prompt_mask is None:
             boolean_prompt_mask = torch.ones(prompt_embeds.shape[:2], dtype=torch.bool, device=prompt_embeds.device)
-        pe, pm = self._pad_text(prompt_embeds.to(self.device), boolean_prompt_mask.to(self.device))
+        # (the mask is NOT moved here: a host mask reaches the engine as a host pointer too, which spares the call its only host sync)
+        pe, pm = self._pad_text(prompt_embeds.to(self.device), boolean_prompt_mask)
         c = inference_scheduler.config
         if seed is None:
             # the reference draws step noise from torch's global generator (randn_tensor in scheduler.step): derive the

@@ -60,9 +60,11 @@ class DataParallelGenerator:
         return t
 
     def generate(self, prompt_embeds: Optional[torch.Tensor], mask: Optional[torch.Tensor], guidance: float,
-                 n_samples: int, seed: Optional[int] = None) -> Optional[np.ndarray]:
+                 n_samples: int, seed: Optional[int] = None, after_compute: Optional[Callable] = None) -> Optional[np.ndarray]:
         """Rank 0 passes the global embeddings ([2B, L, d] when guidance > 1); other ranks pass None.
         `seed`: rank 0's value is used (None: drawn from torch's default generator on rank 0).
+        `after_compute`: called on every rank once this pass's device work is enqueued and before the gather waits for it -- the
+        slot where rank 0 tokenises / encodes the NEXT pass (generate_for_batch_dp), hidden behind this pass's denoise.
         Returns the global int16 waveforms [B, n_samples] on rank 0, None elsewhere."""
         cfg_on = guidance > 1.0
         hdr = torch.zeros(4, dtype=torch.int64, device=self.device)
@@ -84,6 +86,8 @@ class DataParallelGenerator:
             if isinstance(wav, np.ndarray):
                 wav = torch.from_numpy(wav)
             assert wav.dtype == torch.int16 and tuple(wav.shape) == (b_local, n_samples), (wav.dtype, tuple(wav.shape))
+        if after_compute is not None:
+            after_compute()
         if self.world == 1:
             return wav.cpu().numpy() if wav is not None else np.zeros((0, n_samples), np.int16)
         bmax = (B + self.world - 1) // self.world
@@ -120,11 +124,18 @@ def generate_for_batch_dp(prompts: Optional[Sequence[str]], encode: Callable, co
     n = int(n.item())
     per_pass = batch_size * dp.world
     outputs: List[np.ndarray] = []
+    # the text encoder is the serial stage (rank 0 encodes for every rank): pass k+1 is tokenised / encoded while pass k's
+    # denoise is still running on the device (the engine's calls do not wait for the stream), before the gather waits for it
+    nxt = {}
+
+    def encode_pass(k):
+        if dp.rank == 0 and k < n:
+            nxt[k] = encode(list(prompts[k:k + per_pass]), samples, guidance)
+
+    encode_pass(0)
     for k in range(0, n, per_pass):
-        pe = pm = None
-        if dp.rank == 0:
-            pe, pm = encode(list(prompts[k:k + per_pass]), samples, guidance)
-        wav = dp.generate(pe, pm, guidance, n_samples)
+        pe, pm = nxt.pop(k) if dp.rank == 0 else (None, None)
+        wav = dp.generate(pe, pm, guidance, n_samples, after_compute=lambda k=k: encode_pass(k + per_pass))
         if dp.rank == 0:
             outputs += [w for w in wav]
     if dp.rank != 0:
