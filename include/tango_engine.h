@@ -208,6 +208,9 @@ int tango_engine_last_denoise_ms(tango_engine_t* h, float* total_ms, float* per_
  * freed first (hipFree: synchronises the device).  The reference has no counterpart: tango.py:51-64 just re-runs PyTorch eagerly. */
 int tango_engine_set_plan_budget(tango_engine_t* h, uint64_t bytes);
 int tango_engine_plan_stats(tango_engine_t* h, uint64_t* bytes_in_use, int* plans);
+/* frees every cached plan now (the next call of each shape rebuilds its plan); also what a measurement tool calls after
+ * tango_tuning_reload() so that build-time routing decisions are taken again */
+int tango_engine_drop_plans(tango_engine_t* h);
 
 int tango_engine_profile_unet(tango_engine_t* h, int batch2, int text_len, char* report, int report_cap, void* stream);
 /* measurement tools only: re-read the TANGO_* dispatch switches (csrc/tuning.h) from the environment, so that one process can

@@ -186,12 +186,16 @@ struct GemmParams {
 };
 
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s);
-enum GemmRoute : int { ROUTE_NONE = 0, ROUTE_WIDE, ROUTE_STREAM, ROUTE_CONV_WIDE, ROUTE_CONV_HALO, ROUTE_DMA, ROUTE_TILE };
+enum GemmRoute : int { ROUTE_NONE = 0, ROUTE_WIDE, ROUTE_STREAM, ROUTE_CONV_WIDE, ROUTE_CONV_HALO, ROUTE_DMA, ROUTE_TILE, ROUTE_DUO };
 int gemm_route(int dtype, const GemmParams& p);   // which kernel family launch_gemm() picks for this problem
 bool conv_halo_ok(int dtype, const GemmParams& p);
 int launch_conv_halo(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s);
 bool gemm_wide_ok(int dtype, const GemmParams& p);   // 256 x 320 ping-pong LDS-DMA GEMM for the big 16-bit linears (gemm_wide.hip)
 int launch_gemm_wide(int dtype, const GemmParams& p, hipStream_t s);
+bool gemm_duo_ok(int dtype, const GemmParams& p);    // 256 x 160 LDS-DMA GEMM, two workgroups per CU, for the short-K 16-bit linears (gemm_duo.hip)
+int launch_gemm_duo(int dtype, const GemmParams& p, hipStream_t s);
+// a kernel with the LayerNorm folded into the weights takes this problem (else: LayerNorm kernel + plain GEMM)
+inline bool gemm_ln_fold_ok(int dtype, const GemmParams& p);
 bool conv_wide_ok(int dtype, const GemmParams& p);   // 3x3 halo-reuse conv on the 256 x 320 tile (conv_wide.hip)
 int launch_conv_wide(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s);
 int conv_wide_pick_splitk(int dtype, const GemmParams& p);
@@ -204,6 +208,7 @@ int gemm_pick_splitk(int dtype, const GemmParams& p);
 // weight-stationary streaming linear for K*sizeof(T) in {640, 1280} bytes (linear_stream.hip)
 bool linear_stream_ok(int dtype, const GemmParams& p);
 int launch_linear_stream(int dtype, const GemmParams& p, hipStream_t s);
+inline bool gemm_ln_fold_ok(int dtype, const GemmParams& p) { return linear_stream_ok(dtype, p) || gemm_wide_ok(dtype, p) || gemm_duo_ok(dtype, p); }
 int launch_fold_ln(int dtype, const void* W, int64_t Kp, const float* gamma, const float* beta, const float* bias_in, void* Wo,
                    float* bias_out, float* wsum, int N, int K, hipStream_t s);
 

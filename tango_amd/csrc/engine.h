@@ -193,6 +193,7 @@ class Engine {
   int profile_unet(int B2, int L, std::string& report, hipStream_t s);
   // plan-cache budget (bytes of workspace slabs kept alive; default 64 GiB or TANGO_PLAN_BUDGET_MB) and its current use
   void set_plan_budget(size_t bytes) { plan_budget = bytes; }
+  void drop_plans() { const size_t b = plan_budget; plan_budget = 0; (void)make_room(1); plan_budget = b; }   // frees every cached plan
   size_t plan_bytes_in_use() const { return plan_bytes; }
   int plan_count() const;
 

@@ -102,8 +102,9 @@ struct Builder {
     if (o.ln) {
       GemmParams q = p;
       q.W = w.Wln; q.bias = w.bln; q.ln_fold = 1; q.ln_eps = o.ln->eps; q.wsum = w.wsum;
-      if (w.Wln && (linear_stream_ok(dt, q) || gemm_wide_ok(dt, q))) {
-        gemm(q, gemm_route(dt, q) == ROUTE_WIDE ? "linear+ln(wide)" : "linear+ln(stream)");
+      if (w.Wln && gemm_ln_fold_ok(dt, q)) {
+        const int rq = gemm_route(dt, q);
+        gemm(q, rq == ROUTE_WIDE ? "linear+ln(wide)" : rq == ROUTE_DUO ? "linear+ln(duo)" : "linear+ln(stream)");
         return;
       }
       // fallback: materialise LayerNorm(x), then the plain GEMM
@@ -116,7 +117,7 @@ struct Builder {
       return;
     }
     const int route = gemm_pick_splitk(dt, p) > 1 ? ROUTE_TILE : gemm_route(dt, p);
-    gemm(p, route == ROUTE_STREAM ? "linear(stream)" : route == ROUTE_WIDE ? "linear(wide)" : "linear");
+    gemm(p, route == ROUTE_STREAM ? "linear(stream)" : route == ROUTE_WIDE ? "linear(wide)" : route == ROUTE_DUO ? "linear(duo)" : "linear");
   }
 
   // 3x3 conv (pad 1) on NHWC: output grid B x H x W; source B x Hin x Win (nearest-upsampled x2 when ups)
@@ -1766,6 +1767,11 @@ void tango_tuning_reload(void) { tango::tuning_reload(); }
 int tango_engine_set_plan_budget(tango_engine_t* h, uint64_t bytes) {
   if (!h) { tango::set_error("tango_engine_set_plan_budget: null engine"); return -1; }
   h->e->set_plan_budget((size_t)bytes);
+  return 0;
+}
+int tango_engine_drop_plans(tango_engine_t* h) {
+  if (!h) { tango::set_error("tango_engine_drop_plans: null engine"); return -1; }
+  h->e->drop_plans();
   return 0;
 }
 int tango_engine_plan_stats(tango_engine_t* h, uint64_t* bytes_in_use, int* plans) {

@@ -358,7 +358,7 @@ int gemm_pick_splitk(int dtype, const GemmParams& p) {
     return 1;
   if (p.mode == GATHER_1D && !(p.taps == 1 && p.rows_pb == p.M && p.in_mul == 1 && p.in_off == 0 && p.out_mul == 1 && p.out_off == 0))
     return 1;
-  if (linear_stream_ok(dtype, p)) return 1;
+  if (gemm_duo_ok(dtype, p) || linear_stream_ok(dtype, p)) return 1;
   if (small_tile_linear(p, dtype == DT_F32 ? 4 : 2)) return 1;      // one launch of 64 x 64 tiles instead (launch_tile)
   {
     const int sw = conv_wide_pick_splitk(dtype, p);    // e.g. 64 tiles of 256 x 320 -> 4 splits = one workgroup per CU
@@ -381,6 +381,7 @@ int gemm_pick_splitk(int dtype, const GemmParams& p) {
 
 // Which kernel family takes this problem (one decision, used by the launcher AND by the per-op profile labels).
 int gemm_route(int dtype, const GemmParams& p) {
+  if (gemm_duo_ok(dtype, p)) return ROUTE_DUO;      // short-K linears: two co-resident workgroups hide each other's pro- and epilogues
   if (!p.ln_fold && gemm_wide_ok(dtype, p)) {
     // the 256 x 320 kernel beats the streaming kernel on plain (no folded LayerNorm) shapes once a row is >= 1280 bytes (round 2:
     // M=65536 N=640 K=640 x20 2.38 -> 1.87 ms), takes the transposed-V and short-row (conv_in im2col, K = 96) shapes the streaming
@@ -402,6 +403,7 @@ int gemm_route(int dtype, const GemmParams& p) {
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
   switch (gemm_route(dtype, p)) {
     case ROUTE_WIDE: return launch_gemm_wide(dtype, p, s);
+    case ROUTE_DUO: return launch_gemm_duo(dtype, p, s);
     case ROUTE_STREAM: return launch_linear_stream(dtype, p, s);
     case ROUTE_CONV_WIDE: return launch_conv_wide(dtype, p, g_zero_page, s);
     case ROUTE_CONV_HALO: return launch_conv_halo(dtype, p, g_zero_page, s);

@@ -178,7 +178,7 @@ int tango_op_linear_ln(int dt, const float* x, const float* w, const float* bias
   p.out = ot; p.ldo = No; p.R = rt; p.ldr = No; p.epi = geglu ? EPI_GEGLU : EPI_NONE;
   p.ln_fold = 1; p.ln_eps = eps; p.wsum = ws;
   TANGO_TRY(gemm_init());
-  if (linear_stream_ok(dt, p) || gemm_wide_ok(dt, p)) {
+  if (gemm_ln_fold_ok(dt, p)) {
     TANGO_TRY(launch_gemm(dt, p, s));
   } else {
     void* nt = sc.get((size_t)M * K * esz);
@@ -219,7 +219,7 @@ int tango_op_linear_qkv(int dt, const float* x, const float* w, const float* gam
     TANGO_TRY(launch_fold_ln(dt, wt, K, gamma, beta, nullptr, wl, bl, ws, N, K, s));
     GemmParams q = p;
     q.W = wl; q.bias = bl; q.ln_fold = 1; q.ln_eps = eps; q.wsum = ws;
-    if (linear_stream_ok(dt, q) || gemm_wide_ok(dt, q)) {
+    if (gemm_ln_fold_ok(dt, q)) {
       TANGO_TRY(launch_gemm(dt, q, s));
     } else {
       void* nt = sc.get((size_t)M * K * esz);

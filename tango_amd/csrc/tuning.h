@@ -24,6 +24,13 @@ struct Tuning {
   bool no_single_key;       // TANGO_NO_SINGLE_KEY=1    A/B: single-key (unconditional-row) cross-attention shortcut out (round 4)
   int wide_prio;            // TANGO_WIDE_PRIO=0..2     A/B: wave priorities in those kernels' ping-pong loops (gemm_wide.hip: PRIO; default 0) (round 4)
   int wide_sched;           // TANGO_WIDE_SCHED=0..1    A/B: where the 256 x 320 kernels issue their LDS-DMAs (gemm_wide.hip: SCH; default 1) (round 4)
+  bool no_stream_ln_geglu;  // TANGO_NO_STREAM_LN_GEGLU=1 A/B: folded-LayerNorm GEGLU projections leave the streaming kernel (LayerNorm kernel + a GEGLU GEMM instead) (round 4)
+  int duo_maxk;             // TANGO_DUO_MAXK=k         gemm_duo_kernel (256 x 160, two workgroups per CU) takes linears with K <= k; 0 = out of the dispatch; unset = the measured rule in gemm_duo_ok() (round 4)
+  int duo_min_tiles;        // TANGO_DUO_MIN_TILES=n    ... that have at least n tiles of 256 x 160
+  int duo_mask;             // TANGO_DUO_MASK=bits      ... of these classes: 1 plain, 2 GEGLU, 4 folded LayerNorm (incl. transposed V), 8 folded LayerNorm + GEGLU
+  int duo_stagger;          // TANGO_DUO_STAGGER=0..3   experiment: delay one of the two first workgroups of every CU (gemm_duo.hip); default 0
+  int duo_delay_pct;        // TANGO_DUO_DELAY_PCT=n    ... by n percent of (k-chunks x 0.5 us)
+  int duo_prio;             // TANGO_DUO_PRIO=0..1      0 = s_setprio 1 around its MFMAs, 1 = no priority changes
 };
 
 inline Tuning read_tuning() {
@@ -38,8 +45,16 @@ inline Tuning read_tuning() {
   x.no_small_tile = on("TANGO_NO_SMALL_TILE");
   x.no_xattn_fused = on("TANGO_NO_XATTN_FUSED");
   x.no_single_key = on("TANGO_NO_SINGLE_KEY");
+  x.no_stream_ln_geglu = on("TANGO_NO_STREAM_LN_GEGLU");
   const char* ws = getenv("TANGO_WIDE_SCHED");
   x.wide_sched = (ws && ws[0] >= '0' && ws[0] <= '1') ? ws[0] - '0' : 1;
+  auto num = [](const char* k, int dflt) { const char* v = getenv(k); return (v && v[0]) ? atoi(v) : dflt; };
+  x.duo_maxk = num("TANGO_DUO_MAXK", -1);
+  x.duo_min_tiles = num("TANGO_DUO_MIN_TILES", 384);
+  x.duo_mask = num("TANGO_DUO_MASK", 7);
+  x.duo_prio = num("TANGO_DUO_PRIO", 0);
+  x.duo_stagger = num("TANGO_DUO_STAGGER", 0);
+  x.duo_delay_pct = num("TANGO_DUO_DELAY_PCT", 100);
   const char* wp = getenv("TANGO_WIDE_PRIO");
   x.wide_prio = (wp && wp[0] >= '0' && wp[0] <= '2') ? wp[0] - '0' : 0;
   return x;

@@ -324,6 +324,10 @@ class Engine:
         """byte budget of the plan cache (workspace slabs kept alive per call shape); least recently used plans are freed first"""
         _lib.check(self.lib.tango_engine_set_plan_budget(self._h, int(nbytes)), "set_plan_budget")
 
+    def drop_plans(self):
+        """free every cached plan (workspace slab + launch program); the next call of each shape rebuilds its own"""
+        _lib.check(self.lib.tango_engine_drop_plans(self._h), "drop_plans")
+
     def plan_stats(self):
         """(bytes of plan workspace alive, number of cached plans)"""
         b, n = C.c_uint64(), C.c_int()

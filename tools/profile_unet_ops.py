@@ -38,6 +38,7 @@ if a.ab:
                 saved[k] = os.environ.get(k)
                 os.environ[k] = v
             e.lib.tango_tuning_reload()
+            e.drop_plans()          # routing decisions taken when a plan is built (split-K, folded LayerNorm or not, labels) follow the arm
             rows = e.profile_unet(2 * a.batch, 64)
             for k, v in saved.items():
                 if v is None:
