@@ -1,14 +1,17 @@
-// 256 x 160 LDS-DMA GEMM, four waves, TWO workgroups per CU (round 4) -- for the short- and mid-K 16-bit linears.
+// 256 x 160 LDS-DMA GEMM, four waves, TWO workgroups per CU (round 4) -- for the 16-bit linears whose grids leave the 8-wave
+// kernels short of tiles.
 //
-// Why: the 256 x 320 kernel (gemm_wide.hip) owns the whole CU (144 KiB of LDS), so every tile's prologue (first chunk latency,
-// 3-4 us) and epilogue (bias / gate / residual / stores at HBM rate, 5-18 us; the GEGLU gate is VALU work) run with the matrix
-// pipe idle, and all 256 CUs do so in step (profiles/r2_wide_trace*.txt).  For K <= 1280 that is 30-50 % of a tile's life.
-// What was tried before and lost: staggered workgroup starts, and a persistent kernel that keeps the next tile's DMAs in flight
-// across the epilogue (vmcnt retires in order: the next tile's first wait also waits for the stores).  Here two INDEPENDENT
-// workgroups share the CU instead: while one sits in its epilogue the other is in its main loop, the hardware arbitrates, and no
-// counter couples them.  The price is LDS traffic per flop: same fragment reads per MFMA as the 256 x 320 tile (waves still own
-// 64 x 160), but 26 KiB of DMA per 160 MFMAs instead of 36 KiB per 320 -- so long-K problems stay on the 8-wave kernel.
-//   * tile 256 x 160, waves 4 (M) x 1 (N), wave tile 64 x 160 = the 256 x 320 kernel's, so its epilogues are used unchanged;
+// The idea it was built for: the 256 x 320 kernel (gemm_wide.hip) owns the whole CU (144 KiB of LDS), so every tile's prologue
+// (first chunk latency, 3-4 us) and epilogue (5-20 us of bias / gate / residual / stores) run with the matrix pipe idle; two
+// INDEPENDENT workgroups per CU could hide each other's pro- and epilogues.  What the GPU said (profiles/r4_c7_duo_*.txt,
+// r4_c8_duo_*.txt): on the big B = 32 grids it only EQUALS the 8-wave kernel (K <= 640) or loses 3-15 % (K >= 1280) -- the
+// partners start together, do the same work at the same speed and stay in step, and forcing a phase offset did not help
+// either; its main loop has no explicit ping-pong and moves 45 % more DMA bytes per flop.  What it is good for: twice as many,
+// half as large tiles.  At B = 8, on the single-key halves at B = 32 and at level 3 the 8-wave kernels have < 2 tiles per CU (or
+// fall back to 4-wave tiles with split-K), and this kernel wins 10-35 % there (B = 8 step 19.7 -> 18.7 ms).  gemm_duo_ok() holds
+// the measured routing rule.
+//   * tile 256 x 160, waves 4 (M) x 1 (N), wave tile 64 x 160 = the 256 x 320 kernel's, so its epilogues are used unchanged and
+//     the results are bit-identical to that kernel's (tests/test_duo_gpu.py);
 //   * 64-byte k-chunks, THREE stages of (256 + 160) rows x 64 B = 78 KiB per workgroup (two fit the 160-KiB LDS);
 //   * ONE barrier per chunk: [ds_read 14 fragments of chunk kc | 40 MFMAs with the DMAs of chunk kc+2 between them | wait for the
 //     own DMAs of chunk kc+1 | barrier].  Chunk kc+2 refills the stage of chunk kc-1, whose reads every wave finished before the
@@ -53,7 +56,7 @@ constexpr int DUO_BM = 256, DUO_BN = 160, DUO_CB = 64, DUO_NST = 3;
 constexpr int DUO_LDS = DUO_NST * (DUO_BM + DUO_BN) * DUO_CB;      // 79872 B: two workgroups per CU
 
 template <typename T, bool GEGLU, bool RES, bool LN, bool VT>
-__global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmParams p, const int prio, const int stagger, const int delay_ticks) {
+__global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmParams p, const int prio) {
   constexpr int BM = DUO_BM, BN = DUO_BN, CB = DUO_CB, NST = DUO_NST;
   constexpr int ROWS = BM + BN, STAGE = ROWS * CB;
   constexpr int RG = ROWS / 16;                  // 16-row groups (1 KiB) per stage: 26
@@ -70,27 +73,6 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmParams p, co
   const int m0 = (bid / NT) * BM, n0 = (bid % NT) * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // Stagger (experiment, TANGO_DUO_STAGGER): the two workgroups that share a CU start together and -- same work, same speed --
-  // stay in step: both in their main loops, then both in their epilogues.  One of the two FIRST workgroups of every CU sleeps for
-  // about half a tile period; later workgroups inherit the offset (a slot is refilled when its workgroup ends).  Which of the
-  // first 512 workgroups is "the second one on its CU": 1 = the second half of them (breadth-first dispatch), 2 = the one whose
-  // wave 0 sits in an odd wave slot of its SIMD (HW_ID.wave_id), 3 = odd position within the XCD (depth-first dispatch).
-  if (stagger != 0 && blockIdx.x < 512u) {
-    bool late;
-    if (stagger == 1) late = blockIdx.x >= 256u;
-    else if (stagger == 3) late = ((blockIdx.x >> 3) & 1u) != 0u;
-    else {
-      unsigned* const flag = (unsigned*)dsm;
-      if (tid == 0) *flag = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) & 1u;
-      __syncthreads();
-      late = *flag != 0u;
-      __syncthreads();
-    }
-    if (late) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)delay_ticks) __builtin_amdgcn_s_sleep(32);
-    }
-  }
 
   // ---- DMA source rows: row group rg = wave + 4 i; i < 4 are activation rows (rg < 16), i >= 4 weight rows, for every wave ----
   const int lrow = lane >> 2;
@@ -202,7 +184,8 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmParams p, co
 // Measured (profiles/r4_c7_duo_*): with >= 512 tiles of 256 x 320 (two or more per CU: every big B = 32 shape) this kernel equals the
 // 8-wave kernel within noise up to K = 640 and loses 3-15 % beyond (its main loop has no explicit ping-pong and moves 45 % more
 // DMA bytes per flop; the two co-resident workgroups start together and stay in step, so their epilogues do NOT hide behind each
-// other's main loops).  It wins where the 8-wave kernels run short of tiles -- B = 8, the single-key halves at B = 32, level 3:
+// other's main loops; delaying one of the two first workgroups of every CU by 0.5 / 1 / 2 x the main-loop time -- picked by dispatch
+// order or by its hardware wave slot -- changed nothing or cost 2-8 %: profiles/r4_c8_duo_stagger_ab_b32.txt).  It wins where the 8-wave kernels run short of tiles -- B = 8, the single-key halves at B = 32, level 3:
 //   M=16384 N=640 K=640 x15 0.546 -> 0.41 ms, M=65536 N=960 K=320 (LN) x5 0.439 -> 0.354, M=8192 N=1280 K=1280 x10 0.49 -> 0.41,
 //   M=4096 N=1280 K=1280 x15 (split-K before) 0.638 -> 0.546; but M=4096 N=1280 K=5120 0.435 -> 0.552, M=65536 N=320 K=1280 0.340 -> 0.391.
 // TANGO_DUO_MAXK >= 0 replaces the rule by "K <= that, >= TANGO_DUO_MIN_TILES tiles" (A/B runs, tests).
@@ -238,10 +221,7 @@ static int launch_duo_cfg(const GemmParams& p, hipStream_t s) {
   auto kfn = gemm_duo_kernel<T, GEGLU, RES, LN, VT>;
   TANGO_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(kfn), DUO_LDS));
   const unsigned grid = (unsigned)((p.M / DUO_BM) * (p.N / DUO_BN));
-  // stagger delay: duo_delay_pct percent of (k-chunks x 0.5 us), in 100-MHz ticks
-  const int nk = p.K * 2 / DUO_CB;
-  const int ticks = (int)((long)nk * 50 * tuning().duo_delay_pct / 100);
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), DUO_LDS, s, p, tuning().duo_prio, grid > 512u ? tuning().duo_stagger : 0, ticks);
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), DUO_LDS, s, p, tuning().duo_prio);
   TANGO_HIP(hipGetLastError());
   return 0;
 }

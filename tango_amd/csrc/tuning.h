@@ -28,8 +28,6 @@ struct Tuning {
   int duo_maxk;             // TANGO_DUO_MAXK=k         gemm_duo_kernel (256 x 160, two workgroups per CU) takes linears with K <= k; 0 = out of the dispatch; unset = the measured rule in gemm_duo_ok() (round 4)
   int duo_min_tiles;        // TANGO_DUO_MIN_TILES=n    ... that have at least n tiles of 256 x 160
   int duo_mask;             // TANGO_DUO_MASK=bits      ... of these classes: 1 plain, 2 GEGLU, 4 folded LayerNorm (incl. transposed V), 8 folded LayerNorm + GEGLU
-  int duo_stagger;          // TANGO_DUO_STAGGER=0..3   experiment: delay one of the two first workgroups of every CU (gemm_duo.hip); default 0
-  int duo_delay_pct;        // TANGO_DUO_DELAY_PCT=n    ... by n percent of (k-chunks x 0.5 us)
   int duo_prio;             // TANGO_DUO_PRIO=0..1      0 = s_setprio 1 around its MFMAs, 1 = no priority changes
 };
 
@@ -53,8 +51,6 @@ inline Tuning read_tuning() {
   x.duo_min_tiles = num("TANGO_DUO_MIN_TILES", 384);
   x.duo_mask = num("TANGO_DUO_MASK", 7);
   x.duo_prio = num("TANGO_DUO_PRIO", 0);
-  x.duo_stagger = num("TANGO_DUO_STAGGER", 0);
-  x.duo_delay_pct = num("TANGO_DUO_DELAY_PCT", 100);
   const char* wp = getenv("TANGO_WIDE_PRIO");
   x.wide_prio = (wp && wp[0] >= '0' && wp[0] <= '2') ? wp[0] - '0' : 0;
   return x;
