@@ -222,7 +222,13 @@ struct GroupNormParams {
   int act;                        // ACT_NONE / ACT_SILU
   float* partial;                 // workspace: [B][chunks][groups][2]
   float* scale_shift;             // workspace: [B][C][2]
+  unsigned* sync = nullptr;       // cross-workgroup barrier words (coop_sync_words() of them, zeroed once, owned by the engine): enables the
+                                  // single-launch cooperative kernel when the whole grid is co-resident; null = always two launches
 };
+// Barrier words for kernels whose workgroups rendezvous inside one launch (norm.hip gn_coop_kernel): [0, 1024) arrival counters,
+// [1024, 2048) generations; self-resetting, so one buffer serves every such launch of ONE stream-ordered sequence.
+constexpr int COOP_SYNC_SLOTS = 1024;
+constexpr int coop_sync_words() { return 2 * COOP_SYNC_SLOTS + 16; }   // + [2048]: sticky timeout flag
 size_t groupnorm_ws_floats(int B, int rows, int C, int groups);
 int launch_groupnorm(int dtype, const GroupNormParams& p, hipStream_t s);
 

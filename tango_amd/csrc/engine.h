@@ -283,6 +283,7 @@ class Engine {
 
   // ---- runtime state ----
   int* d_step = nullptr;
+  unsigned* d_sync = nullptr;   // barrier words of the cooperative kernels (common.h: coop_sync_words()), zeroed once at init
   SchedParams* d_sched = nullptr;   // device copy of the current call's scheduler parameter block
   int64_t* d_ts = nullptr;       // [max_steps]
   float* d_coef = nullptr;       // [max_steps][8]

@@ -150,6 +150,7 @@ struct Builder {
     GroupNormParams p;
     p.x = x.p; p.ldx = x.ld; p.y = out.p; p.ldy = out.ld; p.gamma = w.g; p.beta = w.b;
     p.B = B; p.rows = rows; p.C = w.C; p.groups = groups; p.eps = w.eps; p.act = act;
+    p.sync = E.d_sync;
     const size_t m = A.mark();
     const size_t nf = groupnorm_ws_floats(B, rows, w.C, groups);
     float* ws = alloc_f32(nf);
@@ -821,6 +822,9 @@ int Engine::init() {
     if (v > 0) plan_budget = (size_t)v << 20;
   }
   if (cfg.unet_attn_fp8 && dt == DT_F32) TANGO_FAIL("engine: unet_attn_fp8 needs a 16-bit engine dtype (bf16 / fp16)");
+  d_sync = (unsigned*)dmalloc((size_t)coop_sync_words() * 4);
+  if (!d_sync) return -1;
+  TANGO_HIP(hipMemset(d_sync, 0, (size_t)coop_sync_words() * 4));
   if (cfg.unet_levels > 0) {
     for (int i = 0; i < cfg.unet_levels; ++i)
       if (cfg.unet_channels[i] != cfg.unet_heads[i] * 64) TANGO_FAIL("engine: UNet channels must equal heads * 64 (head_dim 64)");
@@ -1298,6 +1302,10 @@ int Engine::last_denoise_ms(float* total_ms, float* per_step_ms) {
   TANGO_HIP(hipEventElapsedTime(&ms, ev0, ev1));
   if (total_ms) *total_ms = ms;
   if (per_step_ms) *per_step_ms = ms / (float)last_steps;
+  // the work is complete here: a cooperative kernel that gave up waiting for its partners (norm.hip gn_coop_kernel) left a sticky flag
+  unsigned flag = 0;
+  TANGO_HIP(hipMemcpy(&flag, d_sync + 2 * COOP_SYNC_SLOTS, 4, hipMemcpyDeviceToHost));
+  if (flag) TANGO_FAIL("engine: a cooperative kernel timed out at its rendezvous (results of that call are invalid): two engines launching on one GPU at once? set TANGO_NO_GN_COOP=1");
   return 0;
 }
 

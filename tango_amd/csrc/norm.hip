@@ -2,7 +2,12 @@
 // Reference ops replaced: native_group_norm (61/UNet step, 24/VAE), native_layer_norm (48), softmax
 // (VAE AttnBlock, audioldm/variational_autoencoder/modules.py:204-230).
 // Statistics are always fp32; 16-byte vector loads; wave64 shuffle reductions.
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "common.h"
+#include "tuning.h"
 
 namespace tango {
 
@@ -308,9 +313,202 @@ __global__ __launch_bounds__(1024) void gn_fused_small_kernel(const T* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Cooperative single-launch GroupNorm (round 4).  rocprofv3 (profiles/r4_c8_kernel_stats_b1.txt) prices a dispatch inside the
+// hipGraph at 4-5 us and the (sample, group)-per-workgroup kernel above at 16 us per call (64 workgroups, 4-byte strided loads);
+// the two-launch path reads x twice.  Here the grid of the STATISTICS pass keeps its rows in registers across a per-sample
+// rendezvous and normalises them in place of a second launch: one read, one write, one dispatch, 16-byte coalesced accesses.
+//   phase 1  every workgroup loads NV x RPB rows (all loads in flight), reduces per-group (sum, sum of squares) of its rows through
+//            LDS and publishes them to partial[b][chunk][group] with agent-scope stores;
+//   barrier  per sample: arrival counter + generation word (agent-scope atomics; the last arriver resets the counter and bumps
+//            the generation, so the words are back at rest when the kernel ends and serve the next launch of any geometry);
+//   phase 2  every workgroup sums its sample's chunk partials in the fixed order of gn_apply_kernel (double), derives
+//            scale / shift and writes y from the registers.
+// Deadlock rule: workgroups that spin must not keep out workgroups they wait for -- the launcher takes this path only when the
+// WHOLE grid fits the chip at once (occupancy API x CUs, with margin); the spin is bounded (~0.1 s) and raises a sticky flag
+// instead of hanging if that assumption is ever broken (two engines of one process on one GPU launching at the same moment).
+// ------------------------------------------------------------------------------------------
+template <typename T, int NV>
+__global__ __launch_bounds__(256, 4) void gn_coop_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float* __restrict__ partial, unsigned* __restrict__ sync, int rows, int C, int groups,
+                                                      float eps, int act, int VPR, int RPB) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  constexpr int MAXC = 256 * EPV;                     // VPR <= 256 (launcher)
+  // LDS: the per-channel sums of phase 1 and the per-group reductions of phase 2 share one 16-KiB area (a barrier lies between)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * MAXC * 4 > 2 * 2 * 256 * 8 ? 2 * MAXC * 4 : 2 * 2 * 256 * 8];
+  __shared__ float mean_s[256], rstd_s[256];
+  float (*const sm)[MAXC] = (float (*)[MAXC])lds;
+  double (*const part_s)[256] = (double (*)[256])lds;
+  double (*const tot_s)[256] = (double (*)[256])(lds + 2 * 256 * 8);
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
+  const int rl = tid / VPR, tv = tid - rl * VPR;
+  const int cg = C / groups;
+  const int RC = RPB * NV, r0 = chunk * RC;
+  const bool active = rl < RPB;
+  // wave-uniform sample base + 32-bit per-lane byte offsets (a sample is < 4 GiB): no 64-bit address per row in VGPRs
+  const unsigned char* const xb = (const unsigned char*)(x + (int64_t)b * rows * ldx);
+  unsigned char* const yb = (unsigned char*)(y + (int64_t)b * rows * ldy);
+  const unsigned xoff = (unsigned)(((int64_t)(r0 + rl) * ldx + tv * EPV) * (int64_t)sizeof(T)), xstep = (unsigned)((int64_t)RPB * ldx * (int64_t)sizeof(T));
+  const unsigned yoff = (unsigned)(((int64_t)(r0 + rl) * ldy + tv * EPV) * (int64_t)sizeof(T)), ystep = (unsigned)((int64_t)RPB * ldy * (int64_t)sizeof(T));
+  u32x4 v[NV];
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int r = r0 + rl + u * RPB;
+    v[u] = u32x4{0u, 0u, 0u, 0u};
+    if (active && r < rows) v[u] = *(const u32x4*)(xb + (xoff + (unsigned)u * xstep));
+  }
+  float s[EPV], ss[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {       // rows past the end contribute zeros
+    float f[EPV];
+    unpack16<T>(v[u], f);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+  }
+  for (int pass = 0; pass < RPB; ++pass) {
+    if (rl == pass) {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        const int c = tv * EPV + e;
+        if (pass == 0) { sm[0][c] = s[e]; sm[1][c] = ss[e]; }
+        else { sm[0][c] += s[e]; sm[1][c] += ss[e]; }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < groups) {
+    float a = 0.f, q = 0.f;
+    for (int c = tid * cg; c < (tid + 1) * cg; ++c) { a += sm[0][c]; q += sm[1][c]; }
+    float* o = partial + (((int64_t)b * chunks + chunk) * groups + tid) * 2;
+    __hip_atomic_store(o, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(o + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- per-sample rendezvous ----
+  // The partials travel as agent-scope (sc1) stores / loads, i.e. through the coherence point, so the words only need ORDER, not cache
+  // maintenance: every storing thread waits for its stores (vmcnt(0)), the workgroup barrier orders them before thread 0's arrival,
+  // and the poll is a relaxed sc1 load.  Measured (profiles/r4_c11_gn_coop_modes_ab_b*.txt): with acquire loads in the poll loop (one
+  // `buffer_inv sc1` per poll per waiting workgroup while late workgroups are still loading x) the kernel is 2x SLOWER than two
+  // launches at B = 8; with a release arrival + relaxed poll 1.4x; this form 1.2x.  The rendezvous itself costs ~10 us on this
+  // 8-XCD chip -- twice a dispatch (4-5 us) -- so it only pays where it replaces something slower than a second launch: see gn_launch.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    unsigned* const cnt = sync + (b & (COOP_SYNC_SLOTS - 1));
+    unsigned* const gen = sync + COOP_SYNC_SLOTS + (b & (COOP_SYNC_SLOTS - 1));
+    const unsigned g0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // cannot change before everyone arrived
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            // g0 is read BEFORE this workgroup arrives
+    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned)chunks - 1u) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          // the reset lands before the others are released
+      __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      int spins = 0;
+      while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1 << 20)) { __hip_atomic_store(sync + 2 * COOP_SYNC_SLOTS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- per-sample totals: `lanes` threads per group each sum every lanes-th chunk (double, fixed order), as gn_apply_kernel ----
+  int lanes = 256 / groups;
+  if (lanes > 8) lanes = 8;
+  {
+    const int g = tid / lanes, sub = tid - g * lanes;
+    if (g < groups) {
+      double a = 0.0, q = 0.0;
+      for (int ch = sub; ch < chunks; ch += lanes) {
+        const float* o = partial + (((int64_t)b * chunks + ch) * groups + g) * 2;
+        a += (double)__hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q += (double)__hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      part_s[0][tid] = a; part_s[1][tid] = q;
+    }
+    __syncthreads();
+    if (g < groups && sub == 0) {
+      double a = 0.0, q = 0.0;
+      for (int k = 0; k < lanes; ++k) { a += part_s[0][tid + k]; q += part_s[1][tid + k]; }
+      tot_s[0][g] = a; tot_s[1][g] = q;
+    }
+  }
+  __syncthreads();
+  if (tid < groups) {
+    const double n = (double)rows * cg;
+    const double a = tot_s[0][tid], q = tot_s[1][tid];
+    const double mean = a / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_s[tid] = (float)mean;
+    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  if (!active) return;
+  float sc[EPV], sh[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) {
+    const int c = tv * EPV + e;
+    const int g = c / cg;
+    const float s1 = rstd_s[g] * gamma[c];
+    sc[e] = s1; sh[e] = beta[c] - mean_s[g] * s1;
+  }
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int r = r0 + rl + u * RPB;
+    if (r < rows) {
+      float f[EPV];
+      unpack16<T>(v[u], f);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        float t = f[e] * sc[e] + sh[e];
+        if (act == ACT_SILU) t = silu_f(t);
+        f[e] = t;
+      }
+      *(u32x4*)(yb + (yoff + (unsigned)u * ystep)) = pack16<T>(f);
+    }
+  }
+}
+
+// how many workgroups of `kfn` (256 threads, static LDS only) the device holds at once; cached per (kernel, device)
+static int coop_capacity(const void* kfn) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find({kfn, dev});
+  if (it != cache.end()) return it->second;
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, 0) != hipSuccess) per_cu = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+  const int cap = per_cu * cus;
+  cache[{kfn, dev}] = cap;
+  return cap;
+}
+
+template <typename T, int NV>
+static bool gn_coop_try(const GroupNormParams& p, hipStream_t s) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  const int VPR = p.C / EPV;
+  if (VPR > 256 || p.groups > 256 || p.B > COOP_SYNC_SLOTS) return false;
+  const int RPB = 256 / VPR, RC = RPB * NV;
+  const int chunks = (p.rows + RC - 1) / RC;
+  if (chunks > p.rows / 8 + 2 || chunks > 2048) return false;     // the workspace bound of groupnorm_ws_floats
+  auto kfn = gn_coop_kernel<T, NV>;
+  const long cap = coop_capacity(reinterpret_cast<const void*>(kfn));
+  if ((long)p.B * chunks > cap * 3 / 4) return false;             // the whole grid must be co-resident, with room to spare
+  hipLaunchKernelGGL(kfn, dim3((unsigned)chunks, (unsigned)p.B), dim3(256), 0, s, (const T*)p.x, p.ldx, (T*)p.y, p.ldy, p.gamma, p.beta,
+                     p.partial, p.sync, p.rows, p.C, p.groups, p.eps, p.act, VPR, RPB);
+  return true;
+}
+
 size_t groupnorm_ws_floats(int B, int rows, int C, int groups) {
-  // upper bound on B*chunks*groups*2 (chunks <= rows/16 + 1) + B*C*2
-  size_t chunks = (size_t)rows / 16 + 2;
+  // upper bound on B*chunks*groups*2 (two-launch path: chunks <= rows/16 + 1; cooperative kernel: <= rows/8 + 2) + B*C*2
+  size_t chunks = (size_t)rows / 8 + 2;
   if (chunks > 2048 + 2) chunks = 2048 + 2;
   return (size_t)B * chunks * groups * 2 + (size_t)B * C * 2;
 }
@@ -322,6 +520,14 @@ static int gn_launch(const GroupNormParams& p, hipStream_t s) {
   if (p.C / EPV > 256 * GN_NV) TANGO_FAIL("groupnorm: C too large");
   if ((p.ldx * (int64_t)sizeof(T)) % 16 || (p.ldy * (int64_t)sizeof(T)) % 16) TANGO_FAIL("groupnorm: ld alignment");
   const int cg = p.C / p.groups;
+  // Where the cooperative kernel wins (profiles/r4_c11_gn_coop_modes_ab_b1.txt, B = 1): against the (sample, group)-per-workgroup kernel
+  // below on tensors with >= 1024 rows per sample (C=320 rows=4096 x13 0.438 -> 0.227 ms, C=640 rows=1024 x11 0.198 -> 0.162, C=1280
+  // rows=1024 0.034 -> 0.023); at 256 / 64 rows that kernel's 9-13 us beat the ~10-us rendezvous, and against the two-launch path
+  // (tensors > 8 MB: B >= 8) the cooperative kernel loses 5-20 % everywhere.  TANGO_GN_COOP_ALL=1 (tests) lifts the size rule.
+  const bool coop_size = (size_t)p.B * p.rows * p.C * sizeof(T) <= ((size_t)8 << 20) && p.rows >= 1024;
+  if (p.sync && !tuning().no_gn_coop && (coop_size || tuning().gn_coop_all)) {
+    if (gn_coop_try<T, 8>(p, s)) { TANGO_HIP(hipGetLastError()); return 0; }      // (16 rows per thread: 128 VGPRs + spills at 4 waves / SIMD -- same bytes resident, not built)
+  }
   if ((cg & 1) == 0 && (int64_t)p.rows * (cg / 2) <= (int64_t)1024 * GNS_NP && (p.ldx & 1) == 0 && (p.ldy & 1) == 0 &&
       (size_t)p.B * p.rows * p.C * sizeof(T) <= ((size_t)8 << 20)) {
     hipLaunchKernelGGL((gn_fused_small_kernel<T>), dim3((unsigned)p.groups, (unsigned)p.B), dim3(1024), 0, s, (const T*)p.x, p.ldx,

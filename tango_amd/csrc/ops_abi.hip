@@ -307,7 +307,20 @@ int tango_op_groupnorm(int dt, const float* x, const float* gamma, const float* 
   GroupNormParams p;
   p.x = xt; p.ldx = C; p.y = yt; p.ldy = C; p.gamma = gamma; p.beta = beta; p.B = B; p.rows = HW; p.C = C; p.groups = groups;
   p.eps = eps; p.act = act; p.partial = ws; p.scale_shift = ws + (nf - (size_t)B * C * 2);
+  // barrier words of the cooperative kernel: one zeroed buffer per process for these single-stream test entry points
+  static unsigned* op_sync = nullptr;
+  if (!op_sync) {
+    TANGO_HIP(hipMalloc((void**)&op_sync, (size_t)coop_sync_words() * 4));
+    TANGO_HIP(hipMemset(op_sync, 0, (size_t)coop_sync_words() * 4));
+  }
+  p.sync = op_sync;
   TANGO_TRY(launch_groupnorm(dt, p, s));
+  {
+    unsigned flag = 0;
+    TANGO_HIP(hipMemcpyAsync(&flag, op_sync + 2 * COOP_SYNC_SLOTS, 4, hipMemcpyDeviceToHost, s));
+    TANGO_HIP(hipStreamSynchronize(s));
+    if (flag) TANGO_FAIL("op_groupnorm: the cooperative kernel timed out at its rendezvous");
+  }
   TANGO_TRY(launch_nhwc_to_nchw_f32(dt, yt, C, out, B, C, HW, s));
   TANGO_HIP(hipStreamSynchronize(s));
   return 0;

@@ -25,6 +25,8 @@ struct Tuning {
   int wide_prio;            // TANGO_WIDE_PRIO=0..2     A/B: wave priorities in those kernels' ping-pong loops (gemm_wide.hip: PRIO; default 0) (round 4)
   int wide_sched;           // TANGO_WIDE_SCHED=0..1    A/B: where the 256 x 320 kernels issue their LDS-DMAs (gemm_wide.hip: SCH; default 1) (round 4)
   bool no_stream_ln_geglu;  // TANGO_NO_STREAM_LN_GEGLU=1 A/B: folded-LayerNorm GEGLU projections leave the streaming kernel (LayerNorm kernel + a GEGLU GEMM instead) (round 4)
+  bool no_gn_coop;          // TANGO_NO_GN_COOP=1       A/B: cooperative single-launch GroupNorm (norm.hip gn_coop_kernel) out (round 4)
+  bool gn_coop_all;         // TANGO_GN_COOP_ALL=1      tests: that kernel for every geometry it can hold, not only where it was measured faster
   int duo_maxk;             // TANGO_DUO_MAXK=k         gemm_duo_kernel (256 x 160, two workgroups per CU) takes linears with K <= k; 0 = out of the dispatch; unset = the measured rule in gemm_duo_ok() (round 4)
   int duo_min_tiles;        // TANGO_DUO_MIN_TILES=n    ... that have at least n tiles of 256 x 160
   int duo_mask;             // TANGO_DUO_MASK=bits      ... of these classes: 1 plain, 2 GEGLU, 4 folded LayerNorm (incl. transposed V), 8 folded LayerNorm + GEGLU
@@ -44,9 +46,11 @@ inline Tuning read_tuning() {
   x.no_xattn_fused = on("TANGO_NO_XATTN_FUSED");
   x.no_single_key = on("TANGO_NO_SINGLE_KEY");
   x.no_stream_ln_geglu = on("TANGO_NO_STREAM_LN_GEGLU");
+  x.no_gn_coop = on("TANGO_NO_GN_COOP");
   const char* ws = getenv("TANGO_WIDE_SCHED");
   x.wide_sched = (ws && ws[0] >= '0' && ws[0] <= '1') ? ws[0] - '0' : 1;
   auto num = [](const char* k, int dflt) { const char* v = getenv(k); return (v && v[0]) ? atoi(v) : dflt; };
+  x.gn_coop_all = on("TANGO_GN_COOP_ALL");
   x.duo_maxk = num("TANGO_DUO_MAXK", -1);
   x.duo_min_tiles = num("TANGO_DUO_MIN_TILES", 384);
   x.duo_mask = num("TANGO_DUO_MASK", 7);
