@@ -172,6 +172,15 @@ struct GemmParams {
   void* vt = nullptr;
   int vt_n0 = 0, vt_S = 1;
   int64_t vt_ld = 0;
+  // Per-sample row vector for a leading range of rows (round 4; gemm_wide_device.h wide_epilogue only -- the 256 x 320 and 256 x 160
+  // kernels): rows m < rowvec_rows additionally get rowvec[(m / rowvec_per) * N + n] (fp32) and are written to out_lo (row stride
+  // ldo_lo) instead of `out`.  The single-key cross-attention rows of a CFG batch (engine.hip transformer()): attn1's to_out + residual
+  // writes x + attn1 + [to_out2(v_key) + b] for the unconditional samples in one pass.  rowvec_rows % 64 == 0, rowvec_per % 64 == 0.
+  const float* rowvec = nullptr;
+  int64_t rowvec_rows = 0;
+  int rowvec_per = 1;
+  void* out_lo = nullptr;
+  int64_t ldo_lo = 0;
   // LayerNorm folded into the weights (linear_stream.hip): y = rstd*(W'x - mean*wsum) + b'
   int ln_fold = 0;
   float ln_eps = 1e-5f;
@@ -188,6 +197,7 @@ struct GemmParams {
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s);
 enum GemmRoute : int { ROUTE_NONE = 0, ROUTE_WIDE, ROUTE_STREAM, ROUTE_CONV_WIDE, ROUTE_CONV_HALO, ROUTE_DMA, ROUTE_TILE, ROUTE_DUO };
 int gemm_route(int dtype, const GemmParams& p);   // which kernel family launch_gemm() picks for this problem
+bool gemm_rowvec_ok(int dtype, const GemmParams& p);   // the kernel that takes this problem implements GemmParams::rowvec
 bool conv_halo_ok(int dtype, const GemmParams& p);
 int launch_conv_halo(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s);
 bool gemm_wide_ok(int dtype, const GemmParams& p);   // 256 x 320 ping-pong LDS-DMA GEMM for the big 16-bit linears (gemm_wide.hip)

@@ -39,6 +39,13 @@ struct GOpt {
   const WNorm* ln = nullptr;     // apply LayerNorm(ln) to the input rows first (folded when the streaming kernel applies)
   int glu_tanh = 0;              // EPI_GEGLU gate: tanh GELU (T5 gated-gelu) instead of exact-erf GELU
   int pad = 1;                   // conv3x3: top / left zero padding (0 = the VAE Downsample's asymmetric (0,1,0,1) pad)
+  // linear(): rows < rowvec_rows also get rowvec[(row / rowvec_per)][n] and go to out_lo (GemmParams::rowvec); *rowvec_done tells
+  // the caller whether the kernel that takes the problem can do it (else the caller keeps its separate pass)
+  const float* rowvec = nullptr;
+  int64_t rowvec_rows = 0;
+  int rowvec_per = 1;
+  const TView* out_lo = nullptr;
+  bool* rowvec_done = nullptr;
 };
 
 struct Builder {
@@ -115,6 +122,15 @@ struct Builder {
       gemm(p, "linear");
       A.release(m);
       return;
+    }
+    if (o.rowvec && o.rowvec_rows > 0 && !tuning().no_rowvec_fuse) {
+      GemmParams q = p;
+      q.rowvec = o.rowvec; q.rowvec_rows = o.rowvec_rows; q.rowvec_per = o.rowvec_per;
+      q.out_lo = o.out_lo ? o.out_lo->p : p.out; q.ldo_lo = o.out_lo ? o.out_lo->ld : p.ldo;
+      if (gemm_rowvec_ok(dt, q)) {
+        p = q;
+        if (o.rowvec_done) *o.rowvec_done = true;
+      }
     }
     const int route = gemm_pick_splitk(dt, p) > 1 ? ROUTE_TILE : gemm_route(dt, p);
     gemm(p, route == ROUTE_STREAM ? "linear(stream)" : route == ROUTE_WIDE ? "linear(wide)" : route == ROUTE_DUO ? "linear(duo)" : "linear");
@@ -267,7 +283,6 @@ struct Builder {
     attention(slice(qkv, 0, C, esz), slice(qkv, C, C, esz), vt, HW, a, nullptr, B, w.heads, HW, HW, 0.125f, nullptr,
               E.cfg.unet_attn_fp8 != 0 && dt != DT_F32 && HW % 64 == 0);
     TView h1 = alloc(rows, C);
-    { GOpt o; o.residual = &h; linear(a, rows, w.o1, h1, o); }
     TView h2 = h;                       // h is dead after h1 was produced
     const int Lp8 = (L + 7) / 8 * 8;
     // Single-key prefix (round 4): the first `nshort` samples keep exactly one text key, so attn2(norm2(x)) + x is x plus a per-sample
@@ -275,7 +290,15 @@ struct Builder {
     const int ns = cvec ? nshort : 0;
     const int64_t rs = (int64_t)ns * HW, rc = rows - rs;
     auto rows_from = [&](const TView& v, int64_t r0) { TView t = v; t.p = (char*)v.p + (size_t)r0 * v.ld * esz; return t; };
-    if (ns > 0) {
+    // attn1's to_out + residual; where its kernel can, the single-key rows get their constant in the same epilogue and land in h2
+    // directly (in place over the residual h: every element is read and written by the same lane) -- no separate pass over them
+    bool fused_const = false;
+    {
+      GOpt o; o.residual = &h;
+      if (ns > 0) { o.rowvec = cvec; o.rowvec_rows = rs; o.rowvec_per = HW; o.out_lo = &h2; o.rowvec_done = &fused_const; }
+      linear(a, rows, w.o1, h1, o);
+    }
+    if (ns > 0 && !fused_const) {
       const int d = dt, hw = HW, c = C;
       const void* xs = h1.p; void* ys = h2.p; const int64_t lx = h1.ld, ly = h2.ld;
       push([=](hipStream_t s) { return launch_rowbias_add(d, xs, lx, cvec, ys, ly, rs, hw, c, s); },

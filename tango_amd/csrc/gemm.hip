@@ -400,7 +400,18 @@ int gemm_route(int dtype, const GemmParams& p) {
   return ROUTE_TILE;
 }
 
+// can the kernel that will take this problem apply GemmParams::rowvec?  (the engine asks at plan-build time; launch_gemm re-checks)
+bool gemm_rowvec_ok(int dtype, const GemmParams& p) {
+  if (p.epi != EPI_NONE || p.splitk > 1 || gemm_pick_splitk(dtype, p) > 1) return false;
+  if (p.rowvec_rows % 64 != 0 || p.rowvec_per % 64 != 0 || p.rowvec_rows > p.M) return false;
+  if (p.out_lo && (p.ldo_lo % 8 != 0 || ((uintptr_t)p.out_lo & 15))) return false;
+  if ((uintptr_t)p.rowvec & 15) return false;
+  const int r = gemm_route(dtype, p);
+  return r == ROUTE_WIDE || r == ROUTE_DUO;
+}
+
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
+  if (p.rowvec && !gemm_rowvec_ok(dtype, p)) TANGO_FAIL("gemm: rowvec is only implemented by the 256 x 320 / 256 x 160 GEMM epilogues");
   switch (gemm_route(dtype, p)) {
     case ROUTE_WIDE: return launch_gemm_wide(dtype, p, s);
     case ROUTE_DUO: return launch_gemm_duo(dtype, p, s);

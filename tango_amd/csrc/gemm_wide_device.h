@@ -49,16 +49,21 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
   const int l15 = lane & 15, g4 = (lane >> 4) * 4;
   const float* bias2 = p.bias2 ? p.bias2 + (int64_t)(p.step_ptr ? *p.step_ptr : 0) * p.bias2_stride : nullptr;
   float* const cst = (float*)(stage + WIDE_STAGE_BYTES);       // [bias 160 | wsum 160]
+  // rows of the leading range (GemmParams::rowvec): a per-sample vector joins the bias, the output goes to out_lo (wave-uniform: the
+  // wave's 64 rows lie in one sample and on one side of the range boundary)
+  const bool lo = !GEGLU && p.rowvec != nullptr && (int64_t)m_base < p.rowvec_rows;
   if (lane < 40) {
     f32x4 bv = p.bias ? *(const f32x4*)(p.bias + n_base + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     if (bias2) bv += *(const f32x4*)(bias2 + n_base + lane * 4);
+    if (lo) bv += *(const f32x4*)(p.rowvec + (int64_t)(m_base / p.rowvec_per) * p.N + n_base + lane * 4);
     *(f32x4*)(cst + lane * 4) = bv;
     if (LN) *(f32x4*)(cst + 160 + lane * 4) = *(const f32x4*)(p.wsum + n_base + lane * 4);
   }
   __builtin_amdgcn_wave_barrier();
   const int ocol0 = GEGLU ? (n_base >> 1) : n_base;
   const T* Rb = (const T*)p.R;
-  T* Ob = (T*)p.out;
+  T* Ob = lo ? (T*)p.out_lo : (T*)p.out;
+  const int64_t ldo = lo ? p.ldo_lo : p.ldo;
   int prow[NIT], pcol[NIT];                            // (row within the pass, first output column) of this lane's piece per iteration
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -117,7 +122,7 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
       for (int e = 0; e < 8; ++e) tv[e] = from_f<T>(f[e]);
       u32x4 o;
       __builtin_memcpy(&o, tv, 16);
-      *(u32x4*)(Ob + (int64_t)(m_base + ps * RPP + prow[it]) * p.ldo + ocol0 + pcol[it]) = o;
+      *(u32x4*)(Ob + (int64_t)(m_base + ps * RPP + prow[it]) * ldo + ocol0 + pcol[it]) = o;
     }
     __builtin_amdgcn_wave_barrier();
   }

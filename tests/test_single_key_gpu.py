@@ -71,3 +71,35 @@ def test_full_size_level0_uses_the_fused_block_on_the_conditional_half():
     err = ((out - ref).abs().max() / ref.abs().max()).item()
     print("full-size fp16 UNet forward with the single-key shortcut: rel err vs oracle %.3e" % err)
     assert err <= 1e-2
+
+
+def test_single_key_constant_in_the_to_out_epilogue_equals_the_separate_pass():
+    """At B = 8 (UNet batch 16) attn1's to_out + residual runs on the 256 x 160 / 256 x 320 GEMMs, whose epilogue adds the single-key
+    rows' constant and writes them in place (GemmParams::rowvec) -- the separate rowbias_add pass must disappear from the step's
+    program and the output must agree with the TANGO_NO_ROWVEC_FUSE=1 engine to fp16 rounding (one rounding fewer per site)."""
+    cfg = O.UNET_CONFIG_LARGE
+    g = torch.Generator().manual_seed(33)
+    B2, L = 16, 64
+    x = torch.randn(B2, 8, 256, 16, generator=g).cuda()
+    enc = torch.randn(B2, L, 1024, generator=g).cuda()
+    mask = torch.ones(B2, L, dtype=torch.bool)
+    mask[: B2 // 2] = False
+    mask[: B2 // 2, 0] = True
+    outs, labels = {}, {}
+    for fuse in (1, 0):
+        os.environ["TANGO_NO_ROWVEC_FUSE"] = "0" if fuse else "1"
+        e = Engine(unet=cfg, dtype="fp16")
+        e.lib.tango_tuning_reload()
+        e.load_synthetic(1234)
+        outs[fuse] = e.unet_forward(x, 700, enc, mask.cuda()).float().cpu()
+        labels[fuse] = [r[0] for r in e.profile_unet(B2, L)]
+        del e
+    os.environ.pop("TANGO_NO_ROWVEC_FUSE")
+    from tango_amd import _lib
+    _lib.load().tango_tuning_reload()
+    n_sep = {k: sum(1 for lab in v if lab.startswith("xattn_single_key")) for k, v in labels.items()}
+    print("separate single-key passes per step: fused %d, not fused %d" % (n_sep[1], n_sep[0]))
+    assert n_sep[0] == 16 and n_sep[1] <= 1       # the mid block (1024 rows at this batch) runs on the small tiles: its pass stays
+    d = ((outs[1] - outs[0]).abs().max() / outs[0].abs().max()).item()
+    print("fused vs separate single-key constant: rel diff %.3e" % d)
+    assert torch.isfinite(outs[1]).all() and d <= 3e-3
