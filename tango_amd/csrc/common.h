@@ -185,6 +185,9 @@ struct GemmParams {
   int ln_fold = 0;
   float ln_eps = 1e-5f;
   const float* wsum = nullptr;
+  // ln_fold with the row statistics computed by a separate pass (norm.hip ln_stats_kernel): [M][2] fp32 (mean, rstd).  Only the
+  // 256 x 320 GEMM's GEGLU epilogue takes this (gemm_wide.hip XS): its main loop then carries no statistics VALU at all
+  const float* row_stats = nullptr;
   // split-K (small-M GEMMs that cannot fill 256 CUs): blockIdx.y = split; raw fp32 partials go to
   // ws[split][M][N], a second kernel sums them in fixed order (deterministic) and applies the epilogue
   int splitk = 1;
@@ -244,6 +247,8 @@ int launch_groupnorm(int dtype, const GroupNormParams& p, hipStream_t s);
 
 int launch_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma,
                      const float* beta, int rows, int C, float eps, hipStream_t s);
+// LayerNorm statistics only: stats[row] = (mean, 1 / sqrt(var + eps)), two-pass in registers like launch_layernorm
+int launch_ln_stats(int dtype, const void* x, int64_t ldx, float* stats, int rows, int C, float eps, hipStream_t s);
 
 // ---- attention (head_dim 64) ----
 struct AttnParams {

@@ -114,6 +114,23 @@ struct Builder {
         gemm(q, rq == ROUTE_WIDE ? "linear+ln(wide)" : rq == ROUTE_DUO ? "linear+ln(duo)" : "linear+ln(stream)");
         return;
       }
+      // GEGLU projections the in-loop-statistics kernels do not take (levels 1-2): row statistics in a read-only pass, then the
+      // folded weights on the 256 x 320 GEMM -- LayerNorm(x) is never written (round 4)
+      if (w.Wln && p.epi == EPI_GEGLU && !tuning().no_ln_xstats) {
+        const size_t m = A.mark();
+        float* st = alloc_f32((size_t)rows * 2);
+        GemmParams q2 = q;
+        q2.row_stats = st;
+        if (gemm_wide_ok(dt, q2) && gemm_route(dt, q2) == ROUTE_WIDE) {
+          const int d = dt;
+          const void* xp = x.p; const int64_t ldx = x.ld; const int r = (int)rows, c = o.ln->C; const float eps = o.ln->eps;
+          push([=](hipStream_t s) { return launch_ln_stats(d, xp, ldx, st, r, c, eps, s); }, "ln_stats C=" + std::to_string(c));
+          gemm(q2, "linear+ln(xstats)");
+          A.release(m);
+          return;
+        }
+        A.release(m);
+      }
       // fallback: materialise LayerNorm(x), then the plain GEMM
       const size_t m = A.mark();
       TView t = alloc(rows, o.ln->C);

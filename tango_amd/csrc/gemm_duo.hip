@@ -194,7 +194,7 @@ bool gemm_duo_ok(int dtype, const GemmParams& p) {
   const bool linear = p.mode == GATHER_1D && p.taps == 1 && p.rows_pb == p.M && p.in_mul == 1 && p.in_off == 0 && p.out_mul == 1 &&
                       p.out_off == 0 && p.Lin >= p.M;
   if (!linear || p.batch != 1 || p.a_act != ACT_NONE || p.bias_rows) return false;
-  if (p.splitk > 1 || p.out_f32 || p.e_act != ACT_NONE) return false;
+  if (p.splitk > 1 || p.out_f32 || p.e_act != ACT_NONE || p.row_stats) return false;
   if (p.ln_fold && (!p.wsum || ((uintptr_t)p.wsum & 15) || p.alpha != 1.f)) return false;
   if (p.epi != EPI_NONE && p.epi != EPI_GEGLU && p.epi != EPI_VT) return false;
   if (p.epi == EPI_VT && (p.R || p.bias2 || p.vt_n0 % 160 != 0 || p.vt_S % 256 != 0 || p.vt_ld % 8 != 0 || ((uintptr_t)p.vt & 15))) return false;

@@ -62,7 +62,10 @@ template <typename T> __device__ __forceinline__ void wide_frag_stats(const u32x
 // part (slower than 1: what is added to the read part of one wave delays the MFMA issue of its SIMD partner).
 // PRIO (run-time, TANGO_WIDE_PRIO): 0 = s_setprio 1 around the MFMAs of every multiply part, 1 = no priority changes,
 // 2 = static priority for the later-dispatched half (MI355X_MICROARCH.md "Two waves per SIMD" item 4).
-template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool SK, int SCH>
+// XS (round 4): folded LayerNorm with the row statistics from a separate read-only pass (GemmParams::row_stats) -- no statistics
+// VALU beside the MFMAs; built for the GEGLU projections of levels 1-2, where the in-loop statistics made the folded form no faster
+// than LayerNorm kernel + plain GEMM.
+template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool SK, int SCH, bool XS = false>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, const int pp_mode, unsigned long long* __restrict__ trace, const int prio) {
   constexpr int BM = 256, BN = 320, CB = 64, NST = 4;
   constexpr int ROWS = BM + BN, STAGE = ROWS * CB;
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
     // ---- multiply part ----
     if (SCH == 0 && more) issue_chunk(kc + NST - 1, st3);
     if (prio == 0) __builtin_amdgcn_s_setprio(1);
-    if (LN) {
+    if (LN && !XS) {
       // row statistics from the activation fragments this wave holds anyway (both column halves compute them: 32 VALU
       // instructions per chunk next to 40 MFMAs)
 #pragma unroll
@@ -209,7 +212,13 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
   if (trace) t_loop = __builtin_amdgcn_s_memrealtime();
 #endif
   float mean[TM] = {0.f, 0.f, 0.f, 0.f}, rstd[TM] = {1.f, 1.f, 1.f, 1.f};
-  if (LN) {
+  if (LN && XS) {
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      const f32x2 st = *(const f32x2*)(p.row_stats + (int64_t)(m0 + wm * TM * 16 + b * 16 + (lane & 15)) * 2);
+      mean[b] = st.x; rstd[b] = st.y;
+    }
+  } else if (LN) {
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
       float sm = ssum[b], sq = ssq[b];
@@ -259,7 +268,8 @@ bool gemm_wide_ok(int dtype, const GemmParams& p) {
   //   narrow projections (N <= 3 C): levels 1-2 gain 25-30 %; level 0 (K = 320) q | k | v^T x5 1.63 -> 1.47 and attn2.to_q x5
   //   0.59 -> 0.53 at M = 262144, but at M = 65536 (B = 8) the q | k | v^T shape is ~6 % slower here (0.405 vs 0.431): K < 640
   //   comes here from 131072 rows on, or when the whole problem is one column of tiles
-  if (p.ln_fold && (p.epi == EPI_GEGLU || (p.K < 640 && p.M < 131072 && p.N > 320))) return false;
+  if (p.row_stats && !(p.ln_fold && p.epi == EPI_GEGLU && !p.R && !p.bias2)) return false;      // XS exists for the GEGLU epilogue only
+  if (p.ln_fold && !p.row_stats && (p.epi == EPI_GEGLU || (p.K < 640 && p.M < 131072 && p.N > 320))) return false;
   if (p.e_act != ACT_NONE) return false;            // (an inlined activation switch per element bloated this kernel 10x: not supported here)
   if (p.M % 256 != 0 || p.N % 320 != 0 || (p.K * 2) % 64 != 0) return false;
   if (p.ldo % 8 != 0 || ((uintptr_t)p.out & 15) || (p.R && (p.ldr % 8 != 0 || ((uintptr_t)p.R & 15)))) return false;
@@ -272,10 +282,10 @@ bool gemm_wide_ok(int dtype, const GemmParams& p) {
   return tuning().force_big_kernels || tiles >= 192;
 }
 
-template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool SK, int SCH>
+template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool SK, int SCH, bool XS = false>
 static int launch_wide_sch(const GemmParams& p, hipStream_t s) {
   constexpr int LDS = 4 * (256 + 320) * 64;
-  auto kfn = gemm_wide_kernel<T, GEGLU, RES, LN, VT, SK, SCH>;
+  auto kfn = gemm_wide_kernel<T, GEGLU, RES, LN, VT, SK, SCH, XS>;
   TANGO_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(kfn), LDS));
   const int pp_mode = 0;   // static half assignment: waves w and w + 4 share a SIMD (tools/simd_probe.hip)
   const unsigned grid = (unsigned)((p.M / 256) * (p.N / 320));
@@ -318,6 +328,7 @@ static int launch_wide_cfg(const GemmParams& p, hipStream_t s) {
 
 template <typename T>
 static int launch_wide_t(const GemmParams& p, hipStream_t s) {
+  if (p.row_stats) return launch_wide_sch<T, true, false, true, false, false, 1, true>(p, s);      // gemm_wide_ok(): GEGLU, no residual
   if (p.epi == EPI_VT) return p.ln_fold ? launch_wide_cfg<T, false, false, true, true>(p, s) : launch_wide_cfg<T, false, false, false, true>(p, s);
   if (p.ln_fold) {
     if (p.epi == EPI_GEGLU) return p.R ? launch_wide_cfg<T, true, true, true>(p, s) : launch_wide_cfg<T, true, false, true>(p, s);

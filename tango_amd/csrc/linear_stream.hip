@@ -373,6 +373,7 @@ static int stream_launch(const GemmParams& p, hipStream_t s) {
 bool linear_stream_ok(int dtype, const GemmParams& p) {
   if (tuning().no_stream && !p.ln_fold) return false;
   if (tuning().no_stream_ln_geglu && p.ln_fold && p.epi == EPI_GEGLU) return false;
+  if (p.row_stats) return false;
   const int esz = dtype == DT_F32 ? 4 : 2;
   const int rowb = p.K * esz;
   if (p.mode != GATHER_1D || p.taps != 1 || p.rows_pb != p.M || p.in_mul != 1 || p.in_off != 0 || p.out_mul != 1 || p.out_off != 0)

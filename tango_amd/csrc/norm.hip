@@ -615,6 +615,54 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
   }
 }
 
+// statistics only (the consumer is a GEMM with the LayerNorm folded into its weights: gemm_wide.hip XS): one wave per row, read once
+template <typename T>
+__global__ __launch_bounds__(256) void ln_stats_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ stats, int rows, int C, float eps) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int VPR = C / EPV;
+  float f[LN_NV][EPV];
+  float sum = 0.f;
+  const T* xr = x + (int64_t)row * ldx;
+#pragma unroll
+  for (int j = 0; j < LN_NV; ++j) {
+    const int v = lane + j * 64;
+    if (v < VPR) {
+      unpack16<T>(*(const u32x4*)(xr + v * EPV), f[j]);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) sum += f[j][e];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_NV; ++j) {
+    const int v = lane + j * 64;
+    if (v < VPR) {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { const float d = f[j][e] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+  if (lane == 0) *(f32x2*)(stats + (int64_t)row * 2) = f32x2{mean, rstd};
+}
+
+int launch_ln_stats(int dtype, const void* x, int64_t ldx, float* stats, int rows, int C, float eps, hipStream_t s) {
+  const int epv = dtype == DT_F32 ? 4 : 8;
+  if (C % epv != 0 || C / epv > 64 * LN_NV) TANGO_FAIL("ln_stats: unsupported C");
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  switch (dtype) {
+    case DT_F32: hipLaunchKernelGGL((ln_stats_kernel<float>), grid, dim3(256), 0, s, (const float*)x, ldx, stats, rows, C, eps); break;
+    case DT_F16: hipLaunchKernelGGL((ln_stats_kernel<f16>), grid, dim3(256), 0, s, (const f16*)x, ldx, stats, rows, C, eps); break;
+    case DT_BF16: hipLaunchKernelGGL((ln_stats_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)x, ldx, stats, rows, C, eps); break;
+    default: TANGO_FAIL("ln_stats: bad dtype");
+  }
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename T>
 static int ln_launch(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta, int rows, int C,
                      float eps, hipStream_t s) {

@@ -5,6 +5,7 @@
 
 #include "../../include/tango_engine.h"
 #include "common.h"
+#include "tuning.h"
 
 namespace tango {
 
@@ -178,8 +179,14 @@ int tango_op_linear_ln(int dt, const float* x, const float* w, const float* bias
   p.out = ot; p.ldo = No; p.R = rt; p.ldr = No; p.epi = geglu ? EPI_GEGLU : EPI_NONE;
   p.ln_fold = 1; p.ln_eps = eps; p.wsum = ws;
   TANGO_TRY(gemm_init());
+  GemmParams px = p;
+  px.row_stats = (float*)sc.get((size_t)M * 2 * 4);
   if (gemm_ln_fold_ok(dt, p)) {
     TANGO_TRY(launch_gemm(dt, p, s));
+  } else if (geglu && !residual && px.row_stats && !tuning().no_ln_xstats && gemm_wide_ok(dt, px) && gemm_route(dt, px) == ROUTE_WIDE) {
+    // the engine's route for the GEGLU projections of levels 1-2: read-only statistics pass + folded weights (gemm_wide.hip XS)
+    TANGO_TRY(launch_ln_stats(dt, xt, K, (float*)px.row_stats, M, K, eps, s));
+    TANGO_TRY(launch_gemm(dt, px, s));
   } else {
     void* nt = sc.get((size_t)M * K * esz);
     if (!nt) TANGO_FAIL("op_linear_ln: alloc");

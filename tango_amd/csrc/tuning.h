@@ -26,6 +26,7 @@ struct Tuning {
   int wide_sched;           // TANGO_WIDE_SCHED=0..1    A/B: where the 256 x 320 kernels issue their LDS-DMAs (gemm_wide.hip: SCH; default 1) (round 4)
   bool no_stream_ln_geglu;  // TANGO_NO_STREAM_LN_GEGLU=1 A/B: folded-LayerNorm GEGLU projections leave the streaming kernel (LayerNorm kernel + a GEGLU GEMM instead) (round 4)
   bool no_rowvec_fuse;      // TANGO_NO_ROWVEC_FUSE=1   A/B: the single-key rows' constant stays a separate pass instead of riding attn1's to_out epilogue (round 4)
+  bool no_ln_xstats;        // TANGO_NO_LN_XSTATS=1     A/B: GEGLU projections of levels 1-2 back to LayerNorm kernel + plain GEMM (instead of ln_stats + folded weights) (round 4)
   bool no_gn_coop;          // TANGO_NO_GN_COOP=1       A/B: cooperative single-launch GroupNorm (norm.hip gn_coop_kernel) out (round 4)
   bool gn_coop_all;         // TANGO_GN_COOP_ALL=1      tests: that kernel for every geometry it can hold, not only where it was measured faster
   int duo_maxk;             // TANGO_DUO_MAXK=k         gemm_duo_kernel (256 x 160, two workgroups per CU) takes linears with K <= k; 0 = out of the dispatch; unset = the measured rule in gemm_duo_ok() (round 4)
@@ -48,6 +49,7 @@ inline Tuning read_tuning() {
   x.no_single_key = on("TANGO_NO_SINGLE_KEY");
   x.no_stream_ln_geglu = on("TANGO_NO_STREAM_LN_GEGLU");
   x.no_gn_coop = on("TANGO_NO_GN_COOP");
+  x.no_ln_xstats = on("TANGO_NO_LN_XSTATS");
   x.no_rowvec_fuse = on("TANGO_NO_ROWVEC_FUSE");
   const char* ws = getenv("TANGO_WIDE_SCHED");
   x.wide_sched = (ws && ws[0] >= '0' && ws[0] <= '1') ? ws[0] - '0' : 1;

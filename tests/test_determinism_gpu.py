@@ -136,6 +136,26 @@ def test_wide_gemm_ln_repeat(lib, dtype, M, N, K, geglu, res, mean):
            (M, No), ref, tol, "wide linear_ln %s M=%d N=%d K=%d" % (dtype, M, N, K))
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("M,N,K,mean", [(16384, 5120, 640, 0.7), (16384, 2560, 1280, -0.3), (65536, 1280, 640, 6.0)])
+def test_wide_gemm_ln_xstats_geglu_repeat(lib, dtype, M, N, K, mean):
+    """round 4: GEGLU projection with the LayerNorm folded into the weights and the row statistics from a read-only pass
+    (ln_stats_kernel + gemm_wide_kernel XS): the shapes of levels 1-2, rows with |mean| >> std"""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = q(torch.randn(M, K, generator=g) * (0.5 if mean > 3 else 1.3) + mean, dtype).cuda()
+    w = q(torch.randn(N, K, generator=g) / K ** 0.5, dtype).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    ga, be = (1 + 0.2 * torch.randn(K, generator=g)).cuda(), (0.3 * torch.randn(K, generator=g)).cuda()
+    h = F.linear(F.layer_norm(x, (K,), ga, be, 1e-5), w, b)
+    v, gt = h.chunk(2, dim=-1)
+    ref = (v * F.gelu(gt)).cpu()
+    del h, v, gt
+    tol = 2 * TOL[dtype] * (4 if mean > 3 else 1)
+    repeat(lib, lambda out: lib.tango_op_linear_ln(DT[dtype], p(x), p(w), p(b), p(ga), p(be), None, p(out), M, N, K, 1,
+                                                   C.c_float(1e-5), None),
+           (M, N // 2), ref, tol, "wide linear_ln xstats %s M=%d N=%d K=%d" % (dtype, M, N, K), reps=20)
+
+
 @pytest.mark.parametrize("dtype", ["fp16", "bf16", "fp32"])
 @pytest.mark.parametrize("B,S,Ch,K,ln", [(16, 4096, 320, 320, 1),     # level 0: streaming kernel (K = 320 rows), scalar V^T stores
                                         (64, 1024, 640, 640, 1),     # level 1: wide GEMM, folded LN, LDS-transposed V^T tiles
