@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "tuning.h"
 
 namespace tango {
 
@@ -404,6 +405,17 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
     // stream, i.e. 1.5-2x fewer L2->LDS bytes per flop) were measured in round 1: 8 waves 10.5 ms vs 9.2 ms per step
     // at Sq = Skv = 4096; 48 or 64 query rows per wave at 2 waves/SIMD: 9.2 / 10.1 ms -- the kernel is VALU (softmax)
     // co-limited, not fill-limited.
+    constexpr int QB = 2;
+    dim3 grid((unsigned)((p.Sq + 64 * QB - 1) / (64 * QB)), (unsigned)p.heads, (unsigned)p.B);
+    if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true, 4, 3>), grid, dim3(256), 0, s, p);
+    else if constexpr (sizeof(T) == 2) {
+      if (p.fp8_pv) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
+    } else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
+  } else if (tuning().attn_qb2_min_wgs > 0 &&
+             (long)((p.Sq + 127) / 128) * p.heads * p.B >= tuning().attn_qb2_min_wgs && p.Sq % 128 == 0) {
+    // short sequences at large batch (levels 1-2 at B >= 8): 32 query rows per wave halve the K / V tile traffic and the workgroup count
+    // once there are enough workgroups to fill the chip anyway (round 4)
     constexpr int QB = 2;
     dim3 grid((unsigned)((p.Sq + 64 * QB - 1) / (64 * QB)), (unsigned)p.heads, (unsigned)p.B);
     if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true, 4, 3>), grid, dim3(256), 0, s, p);

@@ -529,7 +529,7 @@ static int gn_launch(const GroupNormParams& p, hipStream_t s) {
     if (gn_coop_try<T, 8>(p, s)) { TANGO_HIP(hipGetLastError()); return 0; }      // (16 rows per thread: 128 VGPRs + spills at 4 waves / SIMD -- same bytes resident, not built)
   }
   if ((cg & 1) == 0 && (int64_t)p.rows * (cg / 2) <= (int64_t)1024 * GNS_NP && (p.ldx & 1) == 0 && (p.ldy & 1) == 0 &&
-      (size_t)p.B * p.rows * p.C * sizeof(T) <= ((size_t)8 << 20)) {
+      (size_t)p.B * p.rows * p.C * sizeof(T) <= ((size_t)tuning().gn_small_mb << 20)) {
     hipLaunchKernelGGL((gn_fused_small_kernel<T>), dim3((unsigned)p.groups, (unsigned)p.B), dim3(1024), 0, s, (const T*)p.x, p.ldx,
                        (T*)p.y, p.ldy, p.gamma, p.beta, p.rows, p.C, p.groups, p.eps, p.act);
     TANGO_HIP(hipGetLastError());

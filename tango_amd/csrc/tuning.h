@@ -29,6 +29,8 @@ struct Tuning {
   bool no_ln_xstats;        // TANGO_NO_LN_XSTATS=1     A/B: GEGLU projections of levels 1-2 back to LayerNorm kernel + plain GEMM (instead of ln_stats + folded weights) (round 4)
   bool no_gn_coop;          // TANGO_NO_GN_COOP=1       A/B: cooperative single-launch GroupNorm (norm.hip gn_coop_kernel) out (round 4)
   bool gn_coop_all;         // TANGO_GN_COOP_ALL=1      tests: that kernel for every geometry it can hold, not only where it was measured faster
+  int attn_qb2_min_wgs;     // TANGO_ATTN_QB2_MIN_WGS=n attention with Sq <= 512: 32 query rows per wave once that still leaves n workgroups (default 512: level-2 self-attention at B=32 0.319 -> 0.247 ms, profiles/r4_c14_attn_qb2_ab_b32.txt); 0 = never (round 4)
+  int gn_small_mb;          // TANGO_GN_SMALL_MB=n      GroupNorm: the one-launch (sample, group)-per-workgroup kernel up to n MiB of input (default 8)
   int duo_maxk;             // TANGO_DUO_MAXK=k         gemm_duo_kernel (256 x 160, two workgroups per CU) takes linears with K <= k; 0 = out of the dispatch; unset = the measured rule in gemm_duo_ok() (round 4)
   int duo_min_tiles;        // TANGO_DUO_MIN_TILES=n    ... that have at least n tiles of 256 x 160
   int duo_mask;             // TANGO_DUO_MASK=bits      ... of these classes: 1 plain, 2 GEGLU, 4 folded LayerNorm (incl. transposed V), 8 folded LayerNorm + GEGLU
@@ -55,6 +57,8 @@ inline Tuning read_tuning() {
   x.wide_sched = (ws && ws[0] >= '0' && ws[0] <= '1') ? ws[0] - '0' : 1;
   auto num = [](const char* k, int dflt) { const char* v = getenv(k); return (v && v[0]) ? atoi(v) : dflt; };
   x.gn_coop_all = on("TANGO_GN_COOP_ALL");
+  x.attn_qb2_min_wgs = num("TANGO_ATTN_QB2_MIN_WGS", 512);
+  x.gn_small_mb = num("TANGO_GN_SMALL_MB", 8);
   x.duo_maxk = num("TANGO_DUO_MAXK", -1);
   x.duo_min_tiles = num("TANGO_DUO_MIN_TILES", 384);
   x.duo_mask = num("TANGO_DUO_MASK", 7);
