@@ -247,6 +247,210 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Persistent form (round 4): one workgroup per CU walks its tiles (blockIdx.x, + gridDim.x, ...) and requests chunk 0 of the NEXT
+// tile into ring stage 3 -- the one stage the epilogue's staging area [0, 100 KiB) leaves alone -- BEFORE the current tile's
+// epilogue, so the 3-4 us a fresh workgroup spends waiting for its first chunk (profiles/r2_wide_trace2.txt: prologue 3.3-4.3 us of
+// a 31-us K = 640 tile) hide behind the epilogue.  Chunks 1 and 2 follow when the epilogue is done with stages 0-2.
+// Round 2's persistent kernel (tools/experiments/gemm_pers.hip: the whole operand stream continuous, epilogue squeezed into ONE
+// stage, 16 rows per pass) lost 10 %; this one keeps the epilogue as it is and prefetches one chunk.
+// vmcnt: the prefetch pieces are OLDER than every load / store of the epilogue, so "chunk 0 landed" = at most the epilogue's
+// NSTORES (unpredicated, counted) stores outstanding; the epilogue's own counted waits only become stricter.
+// Every tile uses the stages in the order 3, 0, 1, 2, 3, ...  SCH = 1 issue points, s_setprio around the multiply part, static halves.
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool XS>
+__global__ __launch_bounds__(512) void gemm_wide_pers_kernel(const GemmParams p, const int ntiles) {
+  constexpr int BM = 256, BN = 320, CB = 64, NST = 4;
+  constexpr int ROWS = BM + BN, STAGE = ROWS * CB;
+  constexpr int RG = ROWS / 16, RGW = (RG + 7) / 8;
+  constexpr int TM = 4, TN = 10;
+  constexpr int NSTORES = GEGLU ? 10 : 20;       // wide_epilogue: NPASS x NIT = 4 x 5 (GEGLU 2 x 5); wide_epilogue_vt: 2 x 10
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+
+  const int NT = p.N / BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2, half = wave >> 2;
+  auto tile_origin = [&](const int v, int& m0, int& n0) {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = v & 7, idx = v >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // XCD x works through a contiguous range of tiles
+    m0 = (bid / NT) * BM; n0 = (bid % NT) * BN;
+  };
+  const int lrow = lane >> 2;
+  const int pc = (lane & 3) ^ ((4 - (lrow >> 2)) & 3);
+  unsigned r_off[RGW];
+#pragma unroll
+  for (int i = 0; i < RGW; ++i) {
+    const int row = (wave + 8 * i) * 16 + lrow;
+    r_off[i] = i < 2 ? (unsigned)((int64_t)row * p.lda * (int64_t)sizeof(T)) + pc * 16
+                     : (unsigned)((int64_t)(row - BM) * p.Kp * (int64_t)sizeof(T)) + pc * 16;
+  }
+  const int nk = (p.K * (int)sizeof(T)) / CB;
+  const bool has5 = wave < RG - 8 * (RGW - 1);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
+  auto dma = [&](const int i, const unsigned char* sa, const unsigned char* sw, const unsigned ldst) {
+    unsigned o = r_off[i];
+    asm volatile("" : "+v"(o));
+    __builtin_amdgcn_global_load_lds((gptr_t)((i < 2 ? sa : sw) + o), (lptr_t)(uintptr_t)(ldst + (unsigned)i * 8192u), 16, 0, 0);
+  };
+  auto issue_chunk = [&](const unsigned char* At, const unsigned char* Wt, const int kc) {
+    const unsigned char* sa = At + (int64_t)kc * CB;
+    const unsigned char* sw = Wt + (int64_t)kc * CB;
+    const int st = (NST - 1 + kc) & (NST - 1);
+#pragma unroll
+    for (int i = 0; i < RGW; ++i)
+      if (i < RGW - 1 || has5) dma(i, sa, sw, lds0 + st * STAGE + (unsigned)wave * 1024u);
+  };
+  auto wait_inflight = [&](const int chunks) {
+    if (chunks <= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+    if (has5) {
+      if (chunks == 1) wait_vmcnt_lit<RGW>();
+      else wait_vmcnt_lit<2 * RGW>();
+    } else {
+      if (chunks == 1) wait_vmcnt_lit<RGW - 1>();
+      else wait_vmcnt_lit<2 * (RGW - 1)>();
+    }
+  };
+  const int l15 = lane & 15, g = lane >> 4;
+  const int foff = l15 * CB + ((g ^ ((4 - (l15 >> 2)) & 3)) * 16);
+  const int xrow = (wm * TM * 16) * CB + foff;
+  const int wrow = (BM + wn * TN * 16) * CB + foff;
+  const int npro = nk < NST - 1 ? nk : NST - 1;
+
+  int t = blockIdx.x, m0, n0;
+  tile_origin(t, m0, n0);
+  const unsigned char* At = (const unsigned char*)p.A + (int64_t)m0 * p.lda * (int64_t)sizeof(T);
+  const unsigned char* Wt = (const unsigned char*)p.W + (int64_t)n0 * p.Kp * (int64_t)sizeof(T);
+  for (int c = 0; c < npro; ++c) issue_chunk(At, Wt, c);
+  wait_inflight(npro - 1);                              // chunk 0 landed
+  pp_barrier();
+  for (;;) {
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ssum[TM] = {0.f, 0.f, 0.f, 0.f}, ssq[TM] = {0.f, 0.f, 0.f, 0.f};
+    if (half) pp_barrier();                             // the stagger
+    int st = NST - 1;
+    for (int kc = 0; kc < nk; ++kc) {
+      const unsigned char* Xs = dsm + st * STAGE;
+      const int st3 = st == 0 ? NST - 1 : st - 1;
+      u32x4 wf[TN], xf[TM];
+#pragma unroll
+      for (int a = 0; a < TN; ++a) wf[a] = *(const u32x4*)(Xs + wrow + a * 16 * CB);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) xf[b] = *(const u32x4*)(Xs + xrow + b * 16 * CB);
+      const bool more = kc + NST - 1 < nk;
+      const bool more5 = more && has5;
+      const unsigned char* sa = At + (int64_t)(kc + NST - 1) * CB;
+      const unsigned char* sw = Wt + (int64_t)(kc + NST - 1) * CB;
+      const unsigned ldst = lds0 + st3 * STAGE + (unsigned)wave * 1024u;
+      if (kc + 1 < nk) wait_inflight(kc + 2 < nk ? 1 : 0);
+      pp_barrier();
+      __builtin_amdgcn_s_setprio(1);
+      if (LN && !XS) {
+#pragma unroll
+        for (int b = 0; b < TM; ++b) wide_frag_stats<T>(xf[b], ssum[b], ssq[b]);
+      }
+#pragma unroll
+      for (int a = 0; a < TN; ++a) {
+#pragma unroll
+        for (int b = 0; b < TM; ++b) Mma<T>::run(acc[a][b], wf[a], xf[b]);
+        if ((a & 1) == 0) {
+          const int i = a >> 1;
+          __builtin_amdgcn_sched_barrier(0);
+          if (i < RGW - 1 ? more : more5) dma(i, sa, sw, ldst);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      pp_barrier();
+      st = st == NST - 1 ? 0 : st + 1;
+    }
+    if (!half) pp_barrier();
+    __syncthreads();   // every wave is past its last fragment read: stages 0-2 become the staging area, stage 3 takes the next tile's chunk 0
+    const int tn = t + (int)gridDim.x;
+    const bool has_next = tn < ntiles;
+    int m0n = 0, n0n = 0;
+    const unsigned char* Atn = At;
+    const unsigned char* Wtn = Wt;
+    if (has_next) {
+      tile_origin(tn, m0n, n0n);
+      Atn = (const unsigned char*)p.A + (int64_t)m0n * p.lda * (int64_t)sizeof(T);
+      Wtn = (const unsigned char*)p.W + (int64_t)n0n * p.Kp * (int64_t)sizeof(T);
+      issue_chunk(Atn, Wtn, 0);
+    }
+    // the epilogue's per-lane indices must be recomputed per tile: derived from an opaque copy of the lane id, or hipcc hoists them out
+    // of the tile loop and keeps ~25 more VGPRs alive across the main loop (256 + spills)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    float mean[TM] = {0.f, 0.f, 0.f, 0.f}, rstd[TM] = {1.f, 1.f, 1.f, 1.f};
+    if (LN && XS) {
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const f32x2 sv = *(const f32x2*)(p.row_stats + (int64_t)(m0 + wm * TM * 16 + b * 16 + (lane_e & 15)) * 2);
+        mean[b] = sv.x; rstd[b] = sv.y;
+      }
+    } else if (LN) {
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        float sm = ssum[b], sq = ssq[b];
+        sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+        sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+        const float mu = sm / (float)p.K;
+        float var = sq / (float)p.K - mu * mu;
+        var = var < 0.f ? 0.f : var;
+        mean[b] = mu; rstd[b] = rsqrtf(var + p.ln_eps);
+      }
+    }
+    unsigned char* const slice = dsm + wave * (WIDE_STAGE_BYTES + 1280);
+    if (VT && n0 >= p.vt_n0) wide_epilogue_vt<T, LN>(p, acc, mean, rstd, m0 + wm * TM * 16, n0 + wn * TN * 16, lane_e, slice);
+    else wide_epilogue<T, GEGLU, RES, LN>(p, acc, mean, rstd, m0 + wm * TM * 16, n0 + wn * TN * 16, lane_e, slice);
+    if (!has_next) break;
+    wait_vmcnt_lit<NSTORES>();          // everything older than this tile's stores has retired: chunk 0 of the next tile is in stage 3
+    __syncthreads();                    // ... for every wave, and nobody reads the staging area any more
+    for (int c = 1; c < npro; ++c) issue_chunk(Atn, Wtn, c);
+    t = tn; m0 = m0n; n0 = n0n; At = Atn; Wt = Wtn;
+  }
+}
+
+static int wide_pers_grid(long ntiles) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    else cus = 256;
+  }
+  return ntiles < cus ? (int)ntiles : cus;
+}
+
+template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool XS>
+static int launch_wide_pers_cfg(const GemmParams& p, hipStream_t s) {
+  constexpr int LDS = 4 * (256 + 320) * 64;
+  auto kfn = gemm_wide_pers_kernel<T, GEGLU, RES, LN, VT, XS>;
+  TANGO_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(kfn), LDS));
+  const long ntiles = (long)(p.M / 256) * (p.N / 320);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)wide_pers_grid(ntiles)), dim3(512), LDS, s, p, (int)ntiles);
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+// the persistent form takes a problem when it has at least `wide_pers` tiles per CU-workgroup to walk (TANGO_WIDE_PERS; 0 = never)
+template <typename T>
+static int launch_wide_pers_t(const GemmParams& p, hipStream_t s, bool& taken) {
+  taken = true;
+  if (p.row_stats) return launch_wide_pers_cfg<T, true, false, true, false, true>(p, s);
+  if (p.epi == EPI_VT) return p.ln_fold ? launch_wide_pers_cfg<T, false, false, true, true, false>(p, s) : launch_wide_pers_cfg<T, false, false, false, true, false>(p, s);
+  if (p.epi == EPI_GEGLU) {
+    if (!p.R && !p.ln_fold) return launch_wide_pers_cfg<T, true, false, false, false, false>(p, s);
+    taken = false;
+    return 0;
+  }
+  if (p.ln_fold) return p.R ? launch_wide_pers_cfg<T, false, true, true, false, false>(p, s) : launch_wide_pers_cfg<T, false, false, true, false, false>(p, s);
+  return p.R ? launch_wide_pers_cfg<T, false, true, false, false, false>(p, s) : launch_wide_pers_cfg<T, false, false, false, false, false>(p, s);
+}
+
 // which problems: 16-bit linear, plain / GEGLU epilogue into T, whole 256 x 320 tiles, at least NST k-chunks, and enough
 // tiles to fill the chip
 bool gemm_wide_ok(int dtype, const GemmParams& p) {
@@ -339,6 +543,14 @@ static int launch_wide_t(const GemmParams& p, hipStream_t s) {
 }
 
 int launch_gemm_wide(int dtype, const GemmParams& p, hipStream_t s) {
+  const int pers = tuning().wide_pers;
+  if (pers > 0 && p.splitk <= 1 && (long)(p.M / 256) * (p.N / 320) >= (long)pers * wide_pers_grid(1L << 30)) {
+    bool taken = false;
+    int rc = 0;
+    if (dtype == DT_F16) rc = launch_wide_pers_t<f16>(p, s, taken);
+    else if (dtype == DT_BF16) rc = launch_wide_pers_t<bf16>(p, s, taken);
+    if (taken) return rc;
+  }
   switch (dtype) {
     case DT_F16: return launch_wide_t<f16>(p, s);
     case DT_BF16: return launch_wide_t<bf16>(p, s);

@@ -163,3 +163,83 @@ def test_duo_routing_labels(lib):
         rows = e.profile_unet(16, 64)
     labs = {r[0].split(" ")[0] for r in rows}
     assert "linear(duo)" in labs, sorted(labs)
+
+
+# ---- persistent form of the 256 x 320 GEMM (gemm_wide_pers_kernel): one workgroup per CU walks its tiles, the next tile's first chunk is
+# requested behind the epilogue.  Same arithmetic in the same order: bit-equal to the one-tile-per-workgroup kernel. ----
+
+PERS = dict(TANGO_WIDE_PERS=1, TANGO_DUO_MAXK=0)
+NOPERS = dict(TANGO_WIDE_PERS=0, TANGO_DUO_MAXK=0)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("M,N,K,res,geglu", [
+    (65536, 640, 640, 1, 0),        # 512 tiles: two per workgroup, residual epilogue
+    (19200, 2560, 640, 0, 1),       # 600 tiles: 88 workgroups walk three tiles, the rest two; GEGLU epilogue
+    (131072, 320, 64, 1, 0),        # two k-chunks (< ring depth) per tile
+    (131072, 320, 32, 0, 0),        # one
+    (262144, 320, 320, 1, 0),       # four tiles per workgroup (the level-0 linears)
+])
+def test_wide_pers_linear_bit_equal(lib, dtype, M, N, K, res, geglu):
+    g = torch.Generator().manual_seed(M + N + K + res)
+    x = q(torch.randn(M, K, generator=g), dtype).cuda()
+    w = q(torch.randn(N, K, generator=g) / K ** 0.5, dtype).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    No = N // 2 if geglu else N
+    r = q(torch.randn(M, No, generator=g), dtype).cuda() if res else None
+    call = lambda out: lib.tango_op_linear(DT[dtype], p(x), p(w), p(b), p(r), p(out), M, N, K, 0, 0, geglu, None)
+    with tuning(lib, **NOPERS):
+        ref = run(lib, call, (M, No))
+    with tuning(lib, **PERS):
+        out = run(lib, call, (M, No), REPS)
+    assert torch.equal(out, ref), "persistent vs one-shot 256x320 kernel: %d elements differ" % (out != ref).sum().item()
+    h = F.linear(x, w, b)
+    if geglu:
+        v, gt = h.chunk(2, dim=-1)
+        h = v * F.gelu(gt)
+    h = h + r if res else h
+    err = ((out - h).abs().max() / (h.abs().max() + 1e-9)).item()
+    assert err <= TOL[dtype], err
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("M,N,K,geglu,res", [(131072, 960, 320, 0, 1), (65536, 1920, 640, 0, 0), (32768, 5120, 640, 1, 0), (16384, 10240, 1280, 1, 0)])
+def test_wide_pers_linear_ln_bit_equal(lib, dtype, M, N, K, geglu, res):
+    """folded LayerNorm: in-loop statistics (plain / residual epilogue) and the external-statistics GEGLU form (levels 1-2)"""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = q(torch.randn(M, K, generator=g) * 1.3 + 0.7, dtype).cuda()
+    w = q(torch.randn(N, K, generator=g) / K ** 0.5, dtype).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    ga, be = (1 + 0.2 * torch.randn(K, generator=g)).cuda(), (0.3 * torch.randn(K, generator=g)).cuda()
+    No = N // 2 if geglu else N
+    r = q(torch.randn(M, No, generator=g), dtype).cuda() if res else None
+    call = lambda out: lib.tango_op_linear_ln(DT[dtype], p(x), p(w), p(b), p(ga), p(be), p(r), p(out), M, N, K, geglu, C.c_float(1e-5), None)
+    with tuning(lib, **NOPERS):
+        ref = run(lib, call, (M, No))
+    with tuning(lib, **PERS):
+        out = run(lib, call, (M, No), REPS)
+    assert torch.equal(out, ref), "persistent vs one-shot (LN): %d elements differ" % (out != ref).sum().item()
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,S,Ch,K,ln", [(64, 1024, 640, 640, 1), (64, 1024, 640, 640, 0), (128, 256, 1280, 1280, 1)])
+def test_wide_pers_qkv_vt_bit_equal(lib, dtype, B, S, Ch, K, ln):
+    g = torch.Generator().manual_seed(B + S + Ch + K)
+    x = q(torch.randn(B * S, K, generator=g) * 1.2 + 0.4, dtype).cuda()
+    w = q(torch.randn(3 * Ch, K, generator=g) / K ** 0.5, dtype).cuda()
+    ga, be = (1 + 0.2 * torch.randn(K, generator=g)).cuda(), (0.3 * torch.randn(K, generator=g)).cuda()
+
+    def once():
+        oqk = torch.zeros(B * S, 2 * Ch, device="cuda")
+        ovt = torch.zeros(B, Ch, S, device="cuda")
+        rc = lib.tango_op_linear_qkv(DT[dtype], p(x), p(w), p(ga) if ln else None, p(be) if ln else None, p(oqk), p(ovt), B, S, Ch, K,
+                                     C.c_float(1e-5), None)
+        assert rc == 0, lib.tango_last_error().decode()
+        return oqk, ovt
+
+    with tuning(lib, **NOPERS):
+        ref = once()
+    with tuning(lib, **PERS):
+        for rep in range(REPS):
+            o = once()
+            assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]), "repetition %d differs from the one-shot kernel" % rep
