@@ -78,8 +78,13 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // softmax weights by 5-20 %).  P is carried as 2^8 P (so the e4m3 subnormal floor sits at 7.6e-6 instead of 2e-3 of the row
 // maximum -- with 4096 keys most weights are far below 2e-3); the factor cancels in O = (P V) / sum(P) because the row sum is
 // taken of the same scaled values.  V^T is converted while its tile is staged (clamped to the e4m3 range, +-448).
-template <typename T, int QB, bool MASKED, int NW, int MINW, bool PB = false, bool F8 = false>
+// MSUM (round 4): the softmax row sums come from the matrix pipe -- one more MFMA per P^T fragment against a constant fragment whose
+// row 0 is all ones (no LDS: it is a register constant), instead of 32 v_add_f32 per tile and wave in a loop that is VALU-bound
+// (profiles/r4_attention_loop_isa_count.txt: 182 VALU-class instructions per 32 MFMAs).  The sum is then taken of the ROUNDED P the
+// P.V MFMAs consume (fp32 accumulation), i.e. numerator and denominator see the same weights.
+template <typename T, int QB, bool MASKED, int NW, int MINW, bool PB = false, bool F8 = false, bool MSUM = false>
 __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p) {
+  static_assert(!MSUM || (sizeof(T) == 2 && !F8), "matrix-pipe row sums: 16-bit P only");
   static_assert(!PB || MASKED, "position bias rides on the masked path");
   static_assert(!F8 || (sizeof(T) == 2 && !PB), "fp8 P.V: 16-bit engines, no position bias");
   constexpr int NTH = NW * 64;
@@ -122,9 +127,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
   }
 
   f32x4 oacc[QB][4];
+  f32x4 lacc[QB];                       // MSUM: row 0 of this 16 x 16 block = sum over the keys of P^T, per query column
+  u32x4 ones = u32x4{0u, 0u, 0u, 0u};
+  if (MSUM && l15 == 0) { const unsigned o2 = __is_same(T, f16) ? 0x3C003C00u : 0x3F803F80u; ones = u32x4{o2, o2, o2, o2}; }
   float mrow[QB], lrow[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
+    lacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     mrow[qb] = -1.0e30f; lrow[qb] = 0.f;
 #pragma unroll
     for (int db = 0; db < 4; ++db) oacc[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -273,7 +282,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
       // the O / l rescale (alpha == 1 exactly) and its exponential are skipped -- same values, 32 multiplies fewer
       if (__builtin_amdgcn_ballot_w64(mnew > mrow[qb]) != 0ull) {
         const float alpha = __builtin_amdgcn_exp2f(mrow[qb] - mnew);
-        lrow[qb] *= alpha;
+        if (MSUM) lacc[qb] *= alpha;
+        else lrow[qb] *= alpha;
         mrow[qb] = mnew;
 #pragma unroll
         for (int db = 0; db < 4; ++db) oacc[qb][db] *= alpha;
@@ -287,9 +297,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
           const float pv = MASKED ? __builtin_amdgcn_exp2f(sacc[qb][kb][r] - moff)
                                   : __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qb][kb][r], sc2, -moff));
           sacc[qb][kb][r] = pv;
-          rs += pv;
+          if (!MSUM) rs += pv;
         }
-      lrow[qb] += rs;          // per-lane partial of the row sum: the four kv slices of a query are added once, after the loop
+      if (!MSUM) lrow[qb] += rs;          // per-lane partial of the row sum: the four kv slices of a query are added once, after the loop
     }
 
     // ---- O^T += V^T P^T ----
@@ -329,6 +339,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb) AMma<T>::run(oacc[qb][db], vf, pf[qb]);
         }
+        if constexpr (MSUM) {
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) AMma<T>::run(lacc[qb], ones, pf[qb]);
+        }
       }
     } else {
 #pragma unroll
@@ -360,9 +374,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int q = qbase + qb * 16 + l15;
-    float lsum = lrow[qb];
-    lsum += __shfl_xor(lsum, 16);
-    lsum += __shfl_xor(lsum, 32);
+    float lsum;
+    if (MSUM) lsum = __shfl(lacc[qb][0], l15);           // accumulator row 0 lives in lanes 0..15 (g = 0), element 0
+    else {
+      lsum = lrow[qb];
+      lsum += __shfl_xor(lsum, 16);
+      lsum += __shfl_xor(lsum, 32);
+    }
     const float inv = 1.0f / lsum;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
@@ -410,6 +428,7 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
     if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true, 4, 3>), grid, dim3(256), 0, s, p);
     else if constexpr (sizeof(T) == 2) {
       if (p.fp8_pv) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true>), grid, dim3(256), 0, s, p);
+      else if (tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, true>), grid, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
     } else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
   } else if (tuning().attn_qb2_min_wgs > 0 &&
@@ -421,6 +440,7 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
     if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true, 4, 3>), grid, dim3(256), 0, s, p);
     else if constexpr (sizeof(T) == 2) {
       if (p.fp8_pv) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true>), grid, dim3(256), 0, s, p);
+      else if (tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, true>), grid, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
     } else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
   } else {
@@ -429,6 +449,7 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
     if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true, 4, 3>), grid, dim3(256), 0, s, p);
     else if constexpr (sizeof(T) == 2) {
       if (p.fp8_pv) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true>), grid, dim3(256), 0, s, p);
+      else if (tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, true>), grid, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
     } else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
   }

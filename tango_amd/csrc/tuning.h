@@ -32,6 +32,7 @@ struct Tuning {
   int attn_qb2_min_wgs;     // TANGO_ATTN_QB2_MIN_WGS=n attention with Sq <= 512: 32 query rows per wave once that still leaves n workgroups (default 512: level-2 self-attention at B=32 0.319 -> 0.247 ms, profiles/r4_c14_attn_qb2_ab_b32.txt); 0 = never (round 4)
   int gn_small_mb;          // TANGO_GN_SMALL_MB=n      GroupNorm: the one-launch (sample, group)-per-workgroup kernel up to n MiB of input (default 8)
   int wide_pers;            // TANGO_WIDE_PERS=n        256 x 320 GEMM: the persistent form (next tile's first chunk prefetched behind the epilogue) from n tiles per CU on (default 2: linears of a B = 32 step 20.0 -> 19.7 ms, bit-identical results, profiles/r4_c16_wide_pers_ab_b32.txt); 0 = never (round 4)
+  bool attn_msum;           // TANGO_ATTN_MSUM=0|1      unmasked 16-bit attention: softmax row sums on the matrix pipe (attention.hip MSUM; default on: S = 4096 site 8.00 -> 7.79 ms at B = 32, profiles/r4_c17_attn_msum_ab_b32.txt) (round 4)
   int duo_maxk;             // TANGO_DUO_MAXK=k         gemm_duo_kernel (256 x 160, two workgroups per CU) takes linears with K <= k; 0 = out of the dispatch; unset = the measured rule in gemm_duo_ok() (round 4)
   int duo_min_tiles;        // TANGO_DUO_MIN_TILES=n    ... that have at least n tiles of 256 x 160
   int duo_mask;             // TANGO_DUO_MASK=bits      ... of these classes: 1 plain, 2 GEGLU, 4 folded LayerNorm (incl. transposed V), 8 folded LayerNorm + GEGLU
@@ -61,6 +62,7 @@ inline Tuning read_tuning() {
   x.attn_qb2_min_wgs = num("TANGO_ATTN_QB2_MIN_WGS", 512);
   x.gn_small_mb = num("TANGO_GN_SMALL_MB", 8);
   x.wide_pers = num("TANGO_WIDE_PERS", 2);
+  x.attn_msum = num("TANGO_ATTN_MSUM", 1) != 0;
   x.duo_maxk = num("TANGO_DUO_MAXK", -1);
   x.duo_min_tiles = num("TANGO_DUO_MIN_TILES", 384);
   x.duo_mask = num("TANGO_DUO_MASK", 7);
