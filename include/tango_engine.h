@@ -216,6 +216,11 @@ int tango_engine_profile_unet(tango_engine_t* h, int batch2, int text_len, char*
 /* measurement tools only: re-read the TANGO_* dispatch switches (csrc/tuning.h) from the environment, so that one process can
  * time several arms of an A/B back to back (tools/profile_unet_ops.py --ab).  No reference counterpart. */
 void tango_tuning_reload(void);
+/* host-side query, no GPU needed: the kernel family the GEMM dispatcher (csrc/gemm.hip gemm_route) picks for the 16-bit linear
+ * y[M,N] = epi(x[M,K] W[N,K]^T): "wide", "wide+pers", "duo", "stream", "dma", "tile", "tile+splitk", "wide+xstats" (GEGLU with external
+ * LayerNorm statistics), or "layernorm+<route>" when no kernel folds the LayerNorm for that shape.  dtype 1 = fp16, 2 = bf16.
+ * tests/test_routing.py pins the measured routing rules of the UNet's shapes with it.  No reference counterpart. */
+const char* tango_debug_linear_route(int dtype, int M, int N, int K, int geglu, int ln_fold, int residual, int vt);
 
 /* ---- per-operator entry points (parity tests; fp32 reference-layout tensors on device) ---- */
 int tango_op_conv2d(int dtype, const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,

@@ -99,7 +99,7 @@ class DenoiseArgs(C.Structure):
 
 #: every symbol include/tango_engine.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "tango_last_error", "tango_version", "tango_tuning_reload", "tango_engine_create", "tango_engine_destroy",
+    "tango_last_error", "tango_version", "tango_tuning_reload", "tango_debug_linear_route", "tango_engine_create", "tango_engine_destroy",
     "tango_engine_num_weights", "tango_engine_weight_name", "tango_engine_set_weight",
     "tango_engine_finalize_weights", "tango_engine_denoise", "tango_engine_unet_forward", "tango_engine_unet_forward_music",
     "tango_engine_vae_decode", "tango_engine_vae_encode", "tango_engine_vocode", "tango_engine_vocoder_samples", "tango_engine_encode_text",
@@ -148,6 +148,8 @@ def load():
     lib.tango_engine_profile_unet.argtypes = [vp, ci, ci, C.c_char_p, ci, vp]
     lib.tango_engine_set_plan_budget.argtypes = [vp, C.c_uint64]
     lib.tango_engine_drop_plans.argtypes = [vp]
+    lib.tango_debug_linear_route.argtypes = [ci] * 8
+    lib.tango_debug_linear_route.restype = C.c_char_p
     lib.tango_engine_plan_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(ci)]
     lib.tango_op_conv2d.argtypes = [ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
     lib.tango_op_linear.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]

@@ -1,6 +1,7 @@
 // Per-operator C entry points used by the parity tests (tests/test_ops_gpu.py).  Each takes fp32
 // device tensors in the reference's own layout, converts to the engine dtype/layout, runs the SAME
 // kernels the engine plans use, and converts back.  Not on the product hot path.
+#include <string>
 #include <vector>
 
 #include "../../include/tango_engine.h"
@@ -197,6 +198,44 @@ int tango_op_linear_ln(int dt, const float* x, const float* w, const float* bias
   TANGO_TRY(to_f32(dt, ot, No, out, M, No, s));
   TANGO_HIP(hipStreamSynchronize(s));
   return 0;
+}
+
+const char* tango_debug_linear_route(int dt, int M, int N, int K, int geglu, int ln_fold, int residual, int vt) {
+  static thread_local std::string out;
+  void* const dummy = (void*)(uintptr_t)0x10000;           // aligned, never dereferenced: the *_ok() predicates only look at alignment
+  GemmParams p;
+  p.A = dummy; p.lda = K; p.W = dummy; p.Kp = K; p.bias = (const float*)dummy; p.M = M; p.N = N; p.K = K; p.Cin = K;
+  p.mode = GATHER_1D; p.rows_pb = M; p.Lin = M; p.Lout = M;
+  const int No = geglu ? N / 2 : N;
+  p.out = dummy; p.ldo = vt ? 2 * (N / 3) : No;
+  if (residual) { p.R = dummy; p.ldr = No; }
+  p.epi = geglu ? EPI_GEGLU : (vt ? EPI_VT : EPI_NONE);
+  if (vt) { p.vt = dummy; p.vt_n0 = 2 * (N / 3); p.vt_S = 256; p.vt_ld = 256; }
+  auto name = [&](const GemmParams& g) -> std::string {
+    if (gemm_pick_splitk(dt, g) > 1) return "tile+splitk";
+    switch (gemm_route(dt, g)) {
+      case ROUTE_WIDE: {
+        const long tiles = (long)(g.M / 256) * (g.N / 320);
+        if (g.row_stats) return tuning().wide_pers > 0 && tiles >= 256L * tuning().wide_pers ? "wide+xstats+pers" : "wide+xstats";
+        const bool pers_ok = !(g.epi == EPI_GEGLU && (g.R || g.ln_fold));
+        return tuning().wide_pers > 0 && pers_ok && tiles >= 256L * tuning().wide_pers ? "wide+pers" : "wide";
+      }
+      case ROUTE_DUO: return "duo";
+      case ROUTE_STREAM: return "stream";
+      case ROUTE_DMA: return "dma";
+      case ROUTE_TILE: return "tile";
+      default: return "none";
+    }
+  };
+  if (!ln_fold) { out = name(p); return out.c_str(); }
+  GemmParams q = p;
+  q.ln_fold = 1; q.wsum = (const float*)dummy;
+  if (gemm_ln_fold_ok(dt, q)) { out = name(q); return out.c_str(); }
+  GemmParams q2 = q;
+  q2.row_stats = (const float*)dummy;
+  if (geglu && !residual && !tuning().no_ln_xstats && gemm_wide_ok(dt, q2) && gemm_route(dt, q2) == ROUTE_WIDE) { out = name(q2); return out.c_str(); }
+  out = "layernorm+" + name(p);
+  return out.c_str();
 }
 
 int tango_op_linear_qkv(int dt, const float* x, const float* w, const float* gamma, const float* beta, float* out_qk, float* out_vt,
