@@ -1,8 +1,8 @@
 """Long-horizon precision ladder: BASELINE config 2's length -- 100 DDPM steps, B = 1, guidance 3, full-size
 866M UNet -- fp16 and fp32 engines against the fp32 CPU oracle, plus fp16 vs the fp32 engine at config 3's 200 steps.
 
-The 100-step oracle costs minutes of host time, so the test only runs with TANGO_LONG_TESTS=1; the recorded output of the round-3
-run is profiles/r3_long_horizon_ladder.log.  Floors are the 10-step floors of test_parity_full_gpu.py: drift must stay bounded.
+The 100-step oracle costs minutes of host time, so the test only runs with TANGO_LONG_TESTS=1; the recorded outputs are
+profiles/r3_long_horizon_ladder.log and (final round-4 tree) profiles/r4_c20_long_horizon_ladder.log.  Floors are the 10-step floors of test_parity_full_gpu.py: drift must stay bounded.
 """
 import os
 import sys
