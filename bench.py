@@ -135,8 +135,10 @@ def cpu_baseline(args, unet_cfg, vae_cfg, hifi_cfg, sched_cfg):
     sch = O.DDPMOracle(**sched_cfg)
     # thread-count sweep on one UNet forward: torch's default (= all hardware threads) oversubscribes the memory system on
     # big hosts (round 1: 8.25 s/step at 128 threads vs 2.7 s at 8) -- report the BEST the host can do, with its core count
+    # (the all-hardware-threads point is gone -- round 5, VERDICT r4 weak #11: 161-165 s per forward on the 256-thread GPU box, twice,
+    #  i.e. 330 s of the driver's run to re-learn that it loses by 50x; rounds 1-4 recorded it in profiles/*bench*.json)
     ncpu = os.cpu_count() or 1
-    cands = sorted({c for c in (8, 16, 32, 64, ncpu) if 1 <= c <= ncpu})
+    cands = sorted({c for c in (8, 16, 32, 64) if 1 <= c <= ncpu} or {ncpu})
     sweep = {}
     with torch.no_grad():
         O.unet_forward(usd, unet_cfg, torch.cat([lat] * 2), 999, enc, mask, prefix="unet.")   # page-in / thread-pool warm-up
@@ -175,6 +177,7 @@ class Workload:
         from tango_amd.models import AudioDiffusion
         from tango_amd.tango import Tango
         self.unet_cfg = UNET_CONFIG_XL if xl else UNET_CONFIG_LARGE
+        self.dtype = dtype
         self.model = AudioDiffusion(unet_config=self.unet_cfg, dtype=dtype, device=device, attn_fp8=fp8)
         self.model.engine.load_synthetic(args.seed)
         self.model.use_graph = not args.no_graph
@@ -209,7 +212,9 @@ def synthetic_text(Bg, L, d, device):
     mc = torch.ones(Bg, L, dtype=torch.bool)
     mu = torch.zeros(Bg, L, dtype=torch.bool)
     mu[:, 0] = True
-    return torch.cat([unc, cond]).to(device), torch.cat([mu, mc]).to(device)
+    # the mask stays on the HOST, as a tokenizer hands it over: the engine then picks its plan without reading a device copy back
+    # (with a device mask every denoise call started with a D2H copy + stream sync that the product path does not need)
+    return torch.cat([unc, cond]).to(device), torch.cat([mu, mc])
 
 
 def timed_single_gpu(wl, args, batch, denoise_steps):
@@ -227,8 +232,14 @@ def timed_single_gpu(wl, args, batch, denoise_steps):
     assert wav.shape == (batch, wl.n_samples)
     per_step_ms = float(np.mean([m[1] for m in wl.denoise_ms]))
     ach = GFLOP_UNET_PER_PROMPT_STEP * batch / per_step_ms
-    return {"value": batch * AUDIO_SECONDS_PER_SAMPLE / dt, "unit": "audio-seconds/s", "batch": batch, "denoise_steps": denoise_steps,
-            "seconds_per_pass": dt, "denoise_step_launch_ms": per_step_ms, "roofline_frac": ach / 2500.0}
+    peak = PEAK_TFLOPS[wl.dtype]
+    rec = {"value": batch * AUDIO_SECONDS_PER_SAMPLE / dt, "unit": "audio-seconds/s", "batch": batch, "denoise_steps": denoise_steps,
+           "dtype": wl.dtype, "seconds_per_pass": dt, "denoise_step_launch_ms": per_step_ms, "achieved_tflops": ach, "peak_tflops": peak,
+           "roofline_frac": ach / peak}
+    ex = wl.model.engine.last_step_gflop()
+    if ex:
+        rec["executed_gflop_per_launch"] = ex
+    return rec
 
 
 def stub_main(args, world, rank):
@@ -273,6 +284,7 @@ def main():
     assert world == args.gpus, "--gpus %d but the launcher started %d ranks" % (args.gpus, world)
     if os.environ.get("TANGO_BENCH_STUB"):
         return stub_main(args, world, rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # also when an external torchrun started the ranks (dmabuf IPC for RCCL)
     torch.cuda.set_device(local_rank)          # before the process group: RCCL binds its communicator to the current device
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -324,6 +336,7 @@ def main():
         # algorithmic 1606.36 GFLOP per (prompt, step) x B prompts per launch / measured launch duration
         ach = GFLOP_UNET_PER_PROMPT_STEP * B / per_step_ms   # GFLOP / ms == TFLOP/s
         traffic, traffic_src = hbm_traffic(B, args.dtype, args.xl, args.fp8_attn)
+        executed = wl.model.engine.last_step_gflop()     # GFLOP the engine's step program executes per launch (sum over its ops)
         out = {
             "metric": "audio-seconds generated/sec, Tango-full %d-step, batch=%d, guidance=%g" % (args.denoise_steps, B, args.guidance),
             "value": audio_s / dt, "unit": "audio-seconds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -335,8 +348,14 @@ def main():
                        "global_batch": Bg, "text_len": L, "denoise_steps": args.denoise_steps, "parallelism": "dp%d" % world,
                        "rccl_ranks": rccl_ranks,
                        "hipgraph": not args.no_graph, "fp8_attention": bool(args.fp8_attn), "kernel_src_sha16": kernel_source_sha16()},
+            # `achieved` counts the REFERENCE's algorithmic FLOPs (FlopCounterMode on its modules: what a drop-in must deliver per
+            # launch); `executed_gflop` is what this engine's launch actually multiplies (the single-key path skips to_q / QK^T / PV /
+            # to_out of the unconditional half's cross-attention, step-invariant K / V projections are hoisted out of the step):
+            # `executed_tflops` / `executed_frac` price the kernels, `achieved` / `frac` price the job
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                         "frac": ach / PEAK_TFLOPS[args.dtype],
+                         "frac": ach / PEAK_TFLOPS[args.dtype], "achieved_counts": "algorithmic (reference) FLOPs",
+                         "executed_gflop": executed, "executed_tflops": (executed / per_step_ms) if executed else None,
+                         "executed_frac": (executed / per_step_ms / PEAK_TFLOPS[args.dtype]) if executed else None,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "denoise step (one hipGraph replay: UNet forward of %d prompts x 1606.36 GFLOP + fused CFG/scheduler update), %.2f ms/launch by HIP events"
                                    % (B, per_step_ms)},
@@ -353,6 +372,14 @@ def main():
             wl5 = Workload(args, device, True, "bf16", True)
             oc["config5_shard_xl_bf16_fp8attn_b8_200step"] = timed_single_gpu(wl5, args, 8, 200)
             del wl5
+            # the reference's own arithmetic (fp32) at config 3's batch: 20 of the 200 denoise steps (the per-launch time does not depend
+            # on the step count), priced against the 157.3-TFLOP/s f32 MFMA peak -- VERDICT r4 missing #6
+            wl32 = Workload(args, device, False, "fp32", False)
+            oc["config3_fp32_b32_20step"] = timed_single_gpu(wl32, args, 32, 20)
+            r32 = oc["config3_fp32_b32_20step"]
+            r32["value_note"] = "value is for THIS 20-step pass; 200 steps extrapolate to %.3f audio-seconds/s" % (
+                32 * AUDIO_SECONDS_PER_SAMPLE / (r32["seconds_per_pass"] + 180 * r32["denoise_step_launch_ms"] / 1000.0))
+            del wl32
             out["other_configs"] = oc
         if world == 1 and not args.no_cpu_baseline:
             keys = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "prediction_type", "clip_sample", "variance_type")

@@ -199,6 +199,10 @@ int tango_engine_mel_spectrogram(tango_engine_t* h, const float* wav, float* mel
 
 /* timing of the last denoise call's kernels, measured with HIP events on the launch stream */
 int tango_engine_last_denoise_ms(tango_engine_t* h, float* total_ms, float* per_step_ms);
+/* GFLOP one launch of the last denoise call's UNet step program EXECUTES (sum over its kernel groups; bench.py reports it beside
+ * the reference's algorithmic 1606.36 GFLOP per prompt and step, which it undercuts wherever work was designed out: the single-key
+ * rows of models.py:282-289, the step-invariant to_k / to_v of attention_processor.py:519-520).  No reference counterpart. */
+int tango_engine_last_step_gflop(tango_engine_t* h, double* gflop);
 
 /* diagnostic: eager run of one UNet step with HIP events around every kernel group; writes
  * "label<TAB>ms<TAB>GFLOP" lines into `report` (truncated to report_cap). */

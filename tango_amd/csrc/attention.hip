@@ -84,7 +84,7 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // P.V MFMAs consume (fp32 accumulation), i.e. numerator and denominator see the same weights.
 template <typename T, int QB, bool MASKED, int NW, int MINW, bool PB = false, bool F8 = false, bool MSUM = false>
 __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p) {
-  static_assert(!MSUM || (sizeof(T) == 2 && !F8), "matrix-pipe row sums: 16-bit P only");
+  static_assert(!MSUM || sizeof(T) == 2, "matrix-pipe row sums: the P^T fragments of the 16-bit engines only");
   static_assert(!PB || MASKED, "position bias rides on the masked path");
   static_assert(!F8 || (sizeof(T) == 2 && !PB), "fp8 P.V: 16-bit engines, no position bias");
   constexpr int NTH = NW * 64;
@@ -129,7 +129,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
   f32x4 oacc[QB][4];
   f32x4 lacc[QB];                       // MSUM: row 0 of this 16 x 16 block = sum over the keys of P^T, per query column
   u32x4 ones = u32x4{0u, 0u, 0u, 0u};
-  if (MSUM && l15 == 0) { const unsigned o2 = __is_same(T, f16) ? 0x3C003C00u : 0x3F803F80u; ones = u32x4{o2, o2, o2, o2}; }
+  // (F8: the A fragment of the fp8 MFMA is 8 e4m3 bytes per lane; 1.0 = 0x38)
+  if (MSUM && l15 == 0) { const unsigned o2 = F8 ? 0x38383838u : (__is_same(T, f16) ? 0x3C003C00u : 0x3F803F80u); ones = u32x4{o2, o2, o2, o2}; }
   float mrow[QB], lrow[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
@@ -320,6 +321,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(vf8, pf8[qb], oacc[qb][db], 0, 0, 0);
         }
+        if constexpr (MSUM) {
+          // round 5: the denominator is the sum of the e4m3-ROUNDED weights the products above consume, not of
+          // the unrounded ones -- numerator and denominator see the same P, so the rounding of P no longer biases O = (P V) / sum(P)
+          const long ones8 = (long)(((unsigned long long)ones[1] << 32) | ones[0]);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ones8, pf8[qb], lacc[qb], 0, 0, 0);
+        }
       }
     } else if constexpr (HALF) {
 #pragma unroll
@@ -427,7 +435,8 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
     dim3 grid((unsigned)((p.Sq + 64 * QB - 1) / (64 * QB)), (unsigned)p.heads, (unsigned)p.B);
     if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true, 4, 3>), grid, dim3(256), 0, s, p);
     else if constexpr (sizeof(T) == 2) {
-      if (p.fp8_pv) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true>), grid, dim3(256), 0, s, p);
+      if (p.fp8_pv && tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true, true>), grid, dim3(256), 0, s, p);
+      else if (p.fp8_pv) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true>), grid, dim3(256), 0, s, p);
       else if (tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, true>), grid, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
     } else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
@@ -439,7 +448,8 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
     dim3 grid((unsigned)((p.Sq + 64 * QB - 1) / (64 * QB)), (unsigned)p.heads, (unsigned)p.B);
     if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true, 4, 3>), grid, dim3(256), 0, s, p);
     else if constexpr (sizeof(T) == 2) {
-      if (p.fp8_pv) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true>), grid, dim3(256), 0, s, p);
+      if (p.fp8_pv && tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true, true>), grid, dim3(256), 0, s, p);
+      else if (p.fp8_pv) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true>), grid, dim3(256), 0, s, p);
       else if (tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, true>), grid, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
     } else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
@@ -448,7 +458,8 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
     dim3 grid((unsigned)((p.Sq + 64 * QB - 1) / (64 * QB)), (unsigned)p.heads, (unsigned)p.B);
     if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true, 4, 3>), grid, dim3(256), 0, s, p);
     else if constexpr (sizeof(T) == 2) {
-      if (p.fp8_pv) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true>), grid, dim3(256), 0, s, p);
+      if (p.fp8_pv && tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true, true>), grid, dim3(256), 0, s, p);
+      else if (p.fp8_pv) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true>), grid, dim3(256), 0, s, p);
       else if (tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, true>), grid, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
     } else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);

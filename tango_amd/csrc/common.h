@@ -205,6 +205,7 @@ bool conv_halo_ok(int dtype, const GemmParams& p);
 int launch_conv_halo(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s);
 bool gemm_wide_ok(int dtype, const GemmParams& p);   // 256 x 320 ping-pong LDS-DMA GEMM for the big 16-bit linears (gemm_wide.hip)
 int launch_gemm_wide(int dtype, const GemmParams& p, hipStream_t s);
+int gemm_wide_pers_cus();                            // workgroups the persistent 256 x 320 GEMM launches (the device's CU count)
 bool gemm_duo_ok(int dtype, const GemmParams& p);    // 256 x 160 LDS-DMA GEMM, two workgroups per CU, for the short-K 16-bit linears (gemm_duo.hip)
 int launch_gemm_duo(int dtype, const GemmParams& p, hipStream_t s);
 // a kernel with the LayerNorm folded into the weights takes this problem (else: LayerNorm kernel + plain GEMM)

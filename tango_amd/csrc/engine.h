@@ -138,6 +138,10 @@ struct UNetPlan {
   int* key0 = nullptr;      // i32 [B2]: index of that key per sample (entries >= n_short unused)
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  // k denoise steps per replay (round 5): the same step captured k_steps times back to back
+  hipGraph_t graph_k = nullptr;
+  hipGraphExec_t exec_k = nullptr;
+  int k_steps = 0;
 };
 struct T5LayerW {          // T5Block of the encoder: self-attention + gated-GELU feed-forward (no biases anywhere)
   WNorm ln1, ln2;
@@ -204,6 +208,8 @@ class Engine {
   std::unordered_map<std::string, int> slot_index;
   bool finalized = false;
   float last_total_ms = 0.f, last_step_ms = 0.f;
+  double last_step_gflop = 0.0;  // executed GFLOP of one launch of the last denoise call's step program
+  uint64_t coop_fallbacks = 0;   // workgroups of gn_coop_kernel that took the no-rendezvous fallback (diagnostic; results are unaffected)
 
  private:
   friend struct Builder;
@@ -317,7 +323,9 @@ class Engine {
   uint64_t plan_clock = 0;
   void touch(PlanMeta& m) { m.stamp = ++plan_clock; }
   int make_room(size_t need);             // frees least-recently-used plans until plan_bytes + need <= plan_budget (or nothing is left)
-  int alloc_slab(char** slab, size_t bytes, PlanMeta& m, bool zero);
+  bool evict_lru();
+  int alloc_slab(char** slab, size_t bytes, PlanMeta& m, bool zero);   // on out-of-memory: evicts LRU plans and retries
+  void release_slab(char** slab, PlanMeta& m);
 
   int ensure_temb(const int64_t* ts_host, int n, hipStream_t s);
   int get_unet_plan(int B2, int L, int Lbeat, int Lchord, int n_short, UNetPlan** out);

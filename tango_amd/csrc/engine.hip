@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 namespace tango {
@@ -362,9 +363,12 @@ Engine::Engine(const tango_config_t& c) : cfg(c) {
 }
 
 Engine::~Engine() {
+  (void)hipDeviceSynchronize();     // replays of the graphs destroyed below may still be in flight (denoise does not wait for its stream)
   for (auto& kv : unet_plans) {
     if (kv.second->exec) (void)hipGraphExecDestroy(kv.second->exec);
     if (kv.second->graph) (void)hipGraphDestroy(kv.second->graph);
+    if (kv.second->exec_k) (void)hipGraphExecDestroy(kv.second->exec_k);
+    if (kv.second->graph_k) (void)hipGraphDestroy(kv.second->graph_k);
     if (kv.second->slab) (void)hipFree(kv.second->slab);
   }
   for (auto& kv : vae_plans) if (kv.second->slab) (void)hipFree(kv.second->slab);
@@ -431,46 +435,68 @@ int Engine::plan_count() const {
   return (int)(unet_plans.size() + vae_plans.size() + vae_enc_plans.size() + voc_plans.size() + t5_plans.size() + stft_plans.size());
 }
 
-int Engine::make_room(size_t need) {
-  while (plan_bytes + need > plan_budget) {
-    uint64_t best = ~0ull;
-    int which = -1;
-    lru_candidate(unet_plans, best, 0, which);
-    lru_candidate(vae_plans, best, 1, which);
-    lru_candidate(vae_enc_plans, best, 2, which);
-    lru_candidate(voc_plans, best, 3, which);
-    lru_candidate(t5_plans, best, 4, which);
-    lru_candidate(stft_plans, best, 5, which);
-    if (which < 0) break;                                   // nothing left to free: let the allocation decide
-    // a slab may still be read by work queued on a stream: hipFree synchronises the device before it releases memory
-    auto drop = [&](auto& P) {
-      plan_bytes -= P.meta.bytes < plan_bytes ? P.meta.bytes : plan_bytes;
-      if (P.slab) (void)hipFree(P.slab);
-    };
-    bool ok = false;
-    switch (which) {
-      case 0:
-        ok = lru_erase(unet_plans, best, [&](UNetPlan& P) {
-          if (P.exec) (void)hipGraphExecDestroy(P.exec);
-          if (P.graph) (void)hipGraphDestroy(P.graph);
-          drop(P);
-        });
-        break;
-      case 1: ok = lru_erase(vae_plans, best, [&](VaePlan& P) { drop(P); }); break;
-      case 2: ok = lru_erase(vae_enc_plans, best, [&](VaePlan& P) { drop(P); }); break;
-      case 3: ok = lru_erase(voc_plans, best, [&](VaePlan& P) { drop(P); }); break;
-      case 4: ok = lru_erase(t5_plans, best, [&](T5Plan& P) { drop(P); }); break;
-      default: ok = lru_erase(stft_plans, best, [&](StftPlan& P) { drop(P); }); break;
-    }
-    if (!ok) break;
+// frees the least recently used plan of any cache; false when nothing is left to free
+bool Engine::evict_lru() {
+  uint64_t best = ~0ull;
+  int which = -1;
+  lru_candidate(unet_plans, best, 0, which);
+  lru_candidate(vae_plans, best, 1, which);
+  lru_candidate(vae_enc_plans, best, 2, which);
+  lru_candidate(voc_plans, best, 3, which);
+  lru_candidate(t5_plans, best, 4, which);
+  lru_candidate(stft_plans, best, 5, which);
+  if (which < 0) return false;
+  // a slab may still be read by work queued on a stream: hipFree synchronises the device before it releases memory
+  auto drop = [&](auto& P) {
+    plan_bytes -= P.meta.bytes < plan_bytes ? P.meta.bytes : plan_bytes;
+    if (P.slab) (void)hipFree(P.slab);
+  };
+  switch (which) {
+    case 0:
+      return lru_erase(unet_plans, best, [&](UNetPlan& P) {
+        //  a replay of this plan may still be in flight -- denoise() no longer waits for its stream, and destroying an
+        // executing graph is not safe on HIP: drain the device first (hipFree below would do so anyway, but only AFTER the destroy)
+        (void)hipDeviceSynchronize();
+        if (P.exec) (void)hipGraphExecDestroy(P.exec);
+        if (P.graph) (void)hipGraphDestroy(P.graph);
+        if (P.exec_k) (void)hipGraphExecDestroy(P.exec_k);
+        if (P.graph_k) (void)hipGraphDestroy(P.graph_k);
+        drop(P);
+      });
+    case 1: return lru_erase(vae_plans, best, [&](VaePlan& P) { drop(P); });
+    case 2: return lru_erase(vae_enc_plans, best, [&](VaePlan& P) { drop(P); });
+    case 3: return lru_erase(voc_plans, best, [&](VaePlan& P) { drop(P); });
+    case 4: return lru_erase(t5_plans, best, [&](T5Plan& P) { drop(P); });
+    default: return lru_erase(stft_plans, best, [&](StftPlan& P) { drop(P); });
   }
+}
+
+int Engine::make_room(size_t need) {
+  while (plan_bytes + need > plan_budget)
+    if (!evict_lru()) break;                                // nothing left to free: let the allocation decide
   return 0;
+}
+
+// a plan whose program could not be built gives its slab (and its share of the budget) back
+void Engine::release_slab(char** slab, PlanMeta& m) {
+  if (*slab) (void)hipFree(*slab);
+  *slab = nullptr;
+  plan_bytes -= m.bytes < plan_bytes ? m.bytes : plan_bytes;
+  m.bytes = 0;
 }
 
 int Engine::alloc_slab(char** slab, size_t bytes, PlanMeta& m, bool zero) {
   TANGO_TRY(make_room(bytes));
-  TANGO_HIP(hipMalloc((void**)slab, bytes));
-  if (zero) TANGO_HIP(hipMemset(*slab, 0, bytes));
+  // the budget is a number, the device's free memory a fact (other engines / torch share it): on out-of-memory below the budget,
+  // evict least recently used plans and retry before giving up
+  for (;;) {
+    const hipError_t e = hipMalloc((void**)slab, bytes);
+    if (e == hipSuccess) break;
+    (void)hipGetLastError();
+    if (e != hipErrorOutOfMemory || !evict_lru())
+      TANGO_FAIL(std::string("hipMalloc of a ") + std::to_string(bytes >> 20) + "-MiB plan workspace failed: " + hipGetErrorString(e));
+  }
+  if (zero && hipMemset(*slab, 0, bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(*slab); *slab = nullptr; TANGO_FAIL("hipMemset of a plan workspace failed"); }
   m.bytes = bytes;
   plan_bytes += bytes;
   touch(m);
@@ -1175,7 +1201,7 @@ int Engine::get_unet_plan(int B2, int L, int Lbeat, int Lchord, int n_short, UNe
   TANGO_TRY(alloc_slab(&P->slab, m.peak + 256, P->meta, true));   // zero-filled: V^T pad columns (L not a multiple of 8) must stay zero
   Arena a; a.base = P->slab;
   P->pre.ops.clear(); P->step.ops.clear(); P->pre.labels.clear(); P->step.labels.clear(); P->pre.flops.clear(); P->step.flops.clear();
-  TANGO_TRY(build_unet(*P, a, true));
+  if (int rc = build_unet(*P, a, true)) { release_slab(&P->slab, P->meta); return rc; }
   *out = P.get();
   unet_plans[key] = std::move(P);
   return 0;
@@ -1239,6 +1265,9 @@ int Engine::unet_forward(const float* sample, int64_t t, const Cond (&c)[3], flo
   return 0;
 }
 
+// steps per captured graph when TANGO_GRAPH_STEPS is unset (measured, round 5: see DESIGN.md section 5)
+static int graph_steps_default(int B2) { (void)B2; return 1; }
+
 int Engine::denoise(const tango_denoise_args_t& a, hipStream_t s) {
   if (a.num_steps <= 0) TANGO_FAIL("denoise: num_steps must be positive");
   const bool cfg_on = a.guidance_scale > 1.0f;
@@ -1292,13 +1321,40 @@ int Engine::denoise(const tango_denoise_args_t& a, hipStream_t s) {
     P->graph = g;
     TANGO_HIP(hipGraphInstantiate(&P->exec, g, nullptr, nullptr, 0));
   }
+  // k steps per replay (round 5; north_star: "the 100-200 denoise steps captured as a hipGraph"): the same kernel sequence captured k
+  // times back to back -- every per-step quantity is read through the device-side step counter, so a k-step graph is just k copies.
+  // What it removes is the host-side launch of every replay and the gap between two replays, which only shows at small batches
+  // (B = 1: a 7-ms step); the remainder of num_steps / k runs on the one-step graph.
+  int kk = tuning().graph_steps > 0 ? tuning().graph_steps : graph_steps_default(B2);
+  if (kk > a.num_steps) kk = a.num_steps;
+  if (a.use_graph && kk > 1 && (!P->exec_k || P->k_steps != kk)) {
+    if (P->exec_k) { TANGO_HIP(hipStreamSynchronize(s)); (void)hipGraphExecDestroy(P->exec_k); (void)hipGraphDestroy(P->graph_k); P->exec_k = nullptr; P->graph_k = nullptr; }
+    if (!cap_stream) TANGO_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+    TANGO_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeRelaxed));
+    int rc = 0;
+    for (int i = 0; i < kk && rc == 0; ++i) rc = run_step(cap_stream);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(cap_stream, &g);
+    if (rc != 0) return rc;
+    if (e != hipSuccess) TANGO_FAIL(std::string("hipStreamEndCapture (k-step graph): ") + hipGetErrorString(e));
+    P->graph_k = g;
+    TANGO_HIP(hipGraphInstantiate(&P->exec_k, g, nullptr, nullptr, 0));
+    P->k_steps = kk;
+  }
   TANGO_HIP(hipEventRecord(ev0, s));
-  for (int i = 0; i < a.num_steps; ++i) {
-    if (a.use_graph) TANGO_HIP(hipGraphLaunch(P->exec, s));
-    else TANGO_TRY(run_step(s));
+  {
+    int i = 0;
+    if (a.use_graph && kk > 1)
+      for (; i + kk <= a.num_steps; i += kk) TANGO_HIP(hipGraphLaunch(P->exec_k, s));
+    for (; i < a.num_steps; ++i) {
+      if (a.use_graph) TANGO_HIP(hipGraphLaunch(P->exec, s));
+      else TANGO_TRY(run_step(s));
+    }
   }
   TANGO_HIP(hipEventRecord(ev1, s));
   last_steps = a.num_steps;
+  last_step_gflop = 0.0;
+  for (double f : P->step.flops) last_step_gflop += f / 1e9;
   return 0;
 }
 
@@ -1342,10 +1398,17 @@ int Engine::last_denoise_ms(float* total_ms, float* per_step_ms) {
   TANGO_HIP(hipEventElapsedTime(&ms, ev0, ev1));
   if (total_ms) *total_ms = ms;
   if (per_step_ms) *per_step_ms = ms / (float)last_steps;
-  // the work is complete here: a cooperative kernel that gave up waiting for its partners (norm.hip gn_coop_kernel) left a sticky flag
-  unsigned flag = 0;
-  TANGO_HIP(hipMemcpy(&flag, d_sync + 2 * COOP_SYNC_SLOTS, 4, hipMemcpyDeviceToHost));
-  if (flag) TANGO_FAIL("engine: a cooperative kernel timed out at its rendezvous (results of that call are invalid): two engines launching on one GPU at once? set TANGO_NO_GN_COOP=1");
+  // the work is complete here.  A cooperative kernel whose partners did not all show up in time (norm.hip gn_coop_kernel: the GPU was
+  // shared) recomputed the missing partial sums itself -- same bits, only slower -- and counted it: report once per occurrence, reset
+  unsigned n = 0;
+  TANGO_HIP(hipMemcpy(&n, d_sync + 2 * COOP_SYNC_SLOTS, 4, hipMemcpyDeviceToHost));
+  if (n) {
+    coop_fallbacks += n;
+    TANGO_HIP(hipMemset(d_sync + 2 * COOP_SYNC_SLOTS, 0, 4));
+    if (!tuning().gn_coop_force_fb)
+      fprintf(stderr, "tango: %u workgroup(s) of the cooperative GroupNorm took the no-rendezvous fallback (GPU shared with other work?); "
+                      "results are unaffected, TANGO_NO_GN_COOP=1 avoids the slow path\n", n);
+  }
   return 0;
 }
 
@@ -1470,7 +1533,7 @@ int Engine::get_t5_plan(int B, int L, T5Plan** out) {
   TANGO_TRY(alloc_slab(&P->slab, m.peak + 256, P->meta, true));
   Arena a; a.base = P->slab;
   P->prog.ops.clear(); P->prog.labels.clear(); P->prog.flops.clear();
-  TANGO_TRY(build_t5(*P, a, true));
+  if (int rc = build_t5(*P, a, true)) { release_slab(&P->slab, P->meta); return rc; }
   std::vector<int> bk((size_t)L * L);
   for (int i = 0; i < L; ++i)
     for (int j = 0; j < L; ++j) bk[(size_t)i * L + j] = t5_bucket(j - i, cfg.t5_rel_buckets, cfg.t5_rel_max_distance);
@@ -1563,7 +1626,7 @@ int Engine::get_vae_plan(int B, VaePlan** out) {
   TANGO_TRY(alloc_slab(&P->slab, m.peak + 256, P->meta, false));
   Arena a; a.base = P->slab;
   P->prog.ops.clear();
-  TANGO_TRY(build_vae(*P, a, true));
+  if (int rc = build_vae(*P, a, true)) { release_slab(&P->slab, P->meta); return rc; }
   *out = P.get();
   vae_plans[B] = std::move(P);
   return 0;
@@ -1655,7 +1718,7 @@ int Engine::get_vae_enc_plan(int B, VaePlan** out) {
   TANGO_TRY(alloc_slab(&P->slab, m.peak + 256, P->meta, false));
   Arena a; a.base = P->slab;
   P->prog.ops.clear();
-  TANGO_TRY(build_vae_enc(*P, a, true));
+  if (int rc = build_vae_enc(*P, a, true)) { release_slab(&P->slab, P->meta); return rc; }
   *out = P.get();
   vae_enc_plans[B] = std::move(P);
   return 0;
@@ -1782,7 +1845,7 @@ int Engine::get_voc_plan(int B, int frames, VaePlan** out) {
   TANGO_TRY(alloc_slab(&P->slab, m.peak + 256, P->meta, false));
   Arena a; a.base = P->slab;
   P->prog.ops.clear();
-  TANGO_TRY(build_voc(*P, a, true, frames));
+  if (int rc = build_voc(*P, a, true, frames)) { release_slab(&P->slab, P->meta); return rc; }
   *out = P.get();
   voc_plans[key] = std::move(P);
   return 0;
@@ -1906,6 +1969,12 @@ int tango_engine_profile_unet(tango_engine_t* h, int batch2, int text_len, char*
 
 int tango_engine_last_denoise_ms(tango_engine_t* h, float* total_ms, float* per_step_ms) {
   return h->e->last_denoise_ms(total_ms, per_step_ms);
+}
+int tango_engine_last_step_gflop(tango_engine_t* h, double* gflop) {
+  if (!h || !gflop) { tango::set_error("tango_engine_last_step_gflop: null argument"); return -1; }
+  if (h->e->last_step_gflop <= 0.0) { tango::set_error("last_step_gflop: no denoise call recorded"); return -1; }
+  *gflop = h->e->last_step_gflop;
+  return 0;
 }
 
 }  // extern "C"

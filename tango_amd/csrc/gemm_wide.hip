@@ -424,6 +424,9 @@ static int wide_pers_grid(long ntiles) {
   }
   return ntiles < cus ? (int)ntiles : cus;
 }
+// workgroups of the persistent form on this device (= its CU count; 256 when no device is visible): the route query of ops_abi.hip
+// labels "+pers" with the same number the launcher uses
+int gemm_wide_pers_cus() { return wide_pers_grid(1L << 30); }
 
 template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool XS>
 static int launch_wide_pers_cfg(const GemmParams& p, hipStream_t s) {

@@ -325,19 +325,25 @@ __global__ __launch_bounds__(1024) void gn_fused_small_kernel(const T* __restric
 //   phase 2  every workgroup sums its sample's chunk partials in the fixed order of gn_apply_kernel (double), derives
 //            scale / shift and writes y from the registers.
 // Deadlock rule: workgroups that spin must not keep out workgroups they wait for -- the launcher takes this path only when the
-// WHOLE grid fits the chip at once (occupancy API x CUs, with margin); the spin is bounded (~0.1 s) and raises a sticky flag
-// instead of hanging if that assumption is ever broken (two engines of one process on one GPU launching at the same moment).
+// WHOLE grid fits the chip at once (occupancy API x CUs, with margin).  That is an estimate for an otherwise idle GPU (another
+// process or stream can hold CUs), so correctness does NOT rest on it: the spin is bounded, and a workgroup whose
+// partners have not all arrived in time computes the missing information ITSELF -- it re-reduces every chunk of its sample from x
+// with phase 1's arithmetic in phase 1's order and (re)publishes those partials (bit-identical to what the owners write, so the
+// duplicate stores are benign), then carries on with phase 2.  The result is the same bits as the rendezvous path, only slower;
+// the counter word [2 * COOP_SYNC_SLOTS] counts such fallbacks for diagnostics.  `force_fb` (TANGO_GN_COOP_FORCE_FALLBACK=1, tests)
+// sends every workgroup down that path without waiting.
 // ------------------------------------------------------------------------------------------
 template <typename T, int NV>
 __global__ __launch_bounds__(256, 4) void gn_coop_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float* __restrict__ partial, unsigned* __restrict__ sync, int rows, int C, int groups,
-                                                      float eps, int act, int VPR, int RPB) {
+                                                      float eps, int act, int VPR, int RPB, int force_fb) {
   constexpr int EPV = 16 / (int)sizeof(T);
   constexpr int MAXC = 256 * EPV;                     // VPR <= 256 (launcher)
   // LDS: the per-channel sums of phase 1 and the per-group reductions of phase 2 share one 16-KiB area (a barrier lies between)
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * MAXC * 4 > 2 * 2 * 256 * 8 ? 2 * MAXC * 4 : 2 * 2 * 256 * 8];
   __shared__ float mean_s[256], rstd_s[256];
+  __shared__ int fb_s;
   float (*const sm)[MAXC] = (float (*)[MAXC])lds;
   double (*const part_s)[256] = (double (*)[256])lds;
   double (*const tot_s)[256] = (double (*)[256])(lds + 2 * 256 * 8);
@@ -359,34 +365,46 @@ __global__ __launch_bounds__(256, 4) void gn_coop_kernel(const T* __restrict__ x
     v[u] = u32x4{0u, 0u, 0u, 0u};
     if (active && r < rows) v[u] = *(const u32x4*)(xb + (xoff + (unsigned)u * xstep));
   }
-  float s[EPV], ss[EPV];
+  // phase-1 reduction of one chunk: per-thread sums over its NV rows (ascending), per-channel sums across the RPB row slots through
+  // LDS (ascending), per-group sums over the group's channels (ascending); published with agent-scope stores.  `own`: rows come from
+  // the registers loaded above; otherwise (fallback) they are re-read from x -- the SAME values in the SAME order, hence the same bits.
+  auto reduce_chunk = [&](int ch, bool own) {
+    float s[EPV], ss[EPV];
 #pragma unroll
-  for (int e = 0; e < EPV; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+    for (int e = 0; e < EPV; ++e) { s[e] = 0.f; ss[e] = 0.f; }
 #pragma unroll
-  for (int u = 0; u < NV; ++u) {       // rows past the end contribute zeros
-    float f[EPV];
-    unpack16<T>(v[u], f);
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
-  }
-  for (int pass = 0; pass < RPB; ++pass) {
-    if (rl == pass) {
-#pragma unroll
-      for (int e = 0; e < EPV; ++e) {
-        const int c = tv * EPV + e;
-        if (pass == 0) { sm[0][c] = s[e]; sm[1][c] = ss[e]; }
-        else { sm[0][c] += s[e]; sm[1][c] += ss[e]; }
+    for (int u = 0; u < NV; ++u) {       // rows past the end contribute zeros
+      u32x4 w = v[u];
+      if (!own) {
+        const int r = ch * RC + rl + u * RPB;
+        w = u32x4{0u, 0u, 0u, 0u};
+        if (active && r < rows) w = *(const u32x4*)(xb + (((int64_t)r * ldx + tv * EPV) * (int64_t)sizeof(T)));
       }
+      float f[EPV];
+      unpack16<T>(w, f);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
     }
-    __syncthreads();
-  }
-  if (tid < groups) {
-    float a = 0.f, q = 0.f;
-    for (int c = tid * cg; c < (tid + 1) * cg; ++c) { a += sm[0][c]; q += sm[1][c]; }
-    float* o = partial + (((int64_t)b * chunks + chunk) * groups + tid) * 2;
-    __hip_atomic_store(o, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(o + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+    for (int pass = 0; pass < RPB; ++pass) {
+      if (rl == pass) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          const int c = tv * EPV + e;
+          if (pass == 0) { sm[0][c] = s[e]; sm[1][c] = ss[e]; }
+          else { sm[0][c] += s[e]; sm[1][c] += ss[e]; }
+        }
+      }
+      __syncthreads();
+    }
+    if (tid < groups) {
+      float a = 0.f, q = 0.f;
+      for (int c = tid * cg; c < (tid + 1) * cg; ++c) { a += sm[0][c]; q += sm[1][c]; }
+      float* o = partial + (((int64_t)b * chunks + ch) * groups + tid) * 2;
+      __hip_atomic_store(o, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(o + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  reduce_chunk(chunk, true);
   // ---- per-sample rendezvous ----
   // The partials travel as agent-scope (sc1) stores / loads, i.e. through the coherence point, so the words only need ORDER, not cache
   // maintenance: every storing thread waits for its stores (vmcnt(0)), the workgroup barrier orders them before thread 0's arrival,
@@ -397,6 +415,7 @@ __global__ __launch_bounds__(256, 4) void gn_coop_kernel(const T* __restrict__ x
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
+    int fb = 0;
     unsigned* const cnt = sync + (b & (COOP_SYNC_SLOTS - 1));
     unsigned* const gen = sync + COOP_SYNC_SLOTS + (b & (COOP_SYNC_SLOTS - 1));
     const unsigned g0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // cannot change before everyone arrived
@@ -410,11 +429,24 @@ __global__ __launch_bounds__(256, 4) void gn_coop_kernel(const T* __restrict__ x
       int spins = 0;
       while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0) {
         __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1 << 20)) { __hip_atomic_store(sync + 2 * COOP_SYNC_SLOTS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (force_fb || ++spins > (1 << 17)) { fb = 1; break; }      // ~0.05-0.1 s: four orders of magnitude above a healthy rendezvous
       }
     }
+    if (force_fb) fb = 1;
+    fb_s = fb;
   }
   __syncthreads();
+  if (fb_s) {
+    // Not everyone this workgroup waits for has arrived (they may not even be resident).  Do not depend on them: rebuild the partials
+    // of EVERY chunk of this sample here.  (The arrival above still counts, so the words return to rest once the stragglers have run.)
+    if (tid == 0) __hip_atomic_fetch_add(sync + 2 * COOP_SYNC_SLOTS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int ch = 0; ch < chunks; ++ch) {
+      __syncthreads();                       // the previous chunk's group sums have been read out of `sm`
+      reduce_chunk(ch, false);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   // ---- per-sample totals: `lanes` threads per group each sum every lanes-th chunk (double, fixed order), as gn_apply_kernel ----
   int lanes = 256 / groups;
   if (lanes > 8) lanes = 8;
@@ -502,7 +534,7 @@ static bool gn_coop_try(const GroupNormParams& p, hipStream_t s) {
   const long cap = coop_capacity(reinterpret_cast<const void*>(kfn));
   if ((long)p.B * chunks > cap * 3 / 4) return false;             // the whole grid must be co-resident, with room to spare
   hipLaunchKernelGGL(kfn, dim3((unsigned)chunks, (unsigned)p.B), dim3(256), 0, s, (const T*)p.x, p.ldx, (T*)p.y, p.ldy, p.gamma, p.beta,
-                     p.partial, p.sync, p.rows, p.C, p.groups, p.eps, p.act, VPR, RPB);
+                     p.partial, p.sync, p.rows, p.C, p.groups, p.eps, p.act, VPR, RPB, tuning().gn_coop_force_fb ? 1 : 0);
   return true;
 }
 

@@ -216,9 +216,9 @@ const char* tango_debug_linear_route(int dt, int M, int N, int K, int geglu, int
     switch (gemm_route(dt, g)) {
       case ROUTE_WIDE: {
         const long tiles = (long)(g.M / 256) * (g.N / 320);
-        if (g.row_stats) return tuning().wide_pers > 0 && tiles >= 256L * tuning().wide_pers ? "wide+xstats+pers" : "wide+xstats";
+        if (g.row_stats) return tuning().wide_pers > 0 && tiles >= (long)gemm_wide_pers_cus() * tuning().wide_pers ? "wide+xstats+pers" : "wide+xstats";
         const bool pers_ok = !(g.epi == EPI_GEGLU && (g.R || g.ln_fold));
-        return tuning().wide_pers > 0 && pers_ok && tiles >= 256L * tuning().wide_pers ? "wide+pers" : "wide";
+        return tuning().wide_pers > 0 && pers_ok && tiles >= (long)gemm_wide_pers_cus() * tuning().wide_pers ? "wide+pers" : "wide";
       }
       case ROUTE_DUO: return "duo";
       case ROUTE_STREAM: return "stream";
@@ -365,7 +365,12 @@ int tango_op_groupnorm(int dt, const float* x, const float* gamma, const float* 
     unsigned flag = 0;
     TANGO_HIP(hipMemcpyAsync(&flag, op_sync + 2 * COOP_SYNC_SLOTS, 4, hipMemcpyDeviceToHost, s));
     TANGO_HIP(hipStreamSynchronize(s));
-    if (flag) TANGO_FAIL("op_groupnorm: the cooperative kernel timed out at its rendezvous");
+    if (flag) {
+      // workgroups took the no-rendezvous fallback (results stay valid).  On the idle GPU of a test that only happens on request;
+      // otherwise the barrier words were left in a bad state by an earlier launch, which is what this entry point exists to catch
+      TANGO_HIP(hipMemsetAsync(op_sync + 2 * COOP_SYNC_SLOTS, 0, 4, s));
+      if (!tuning().gn_coop_force_fb) TANGO_FAIL("op_groupnorm: the cooperative kernel gave up waiting at its rendezvous on an idle GPU");
+    }
   }
   TANGO_TRY(launch_nhwc_to_nchw_f32(dt, yt, C, out, B, C, HW, s));
   TANGO_HIP(hipStreamSynchronize(s));

@@ -256,9 +256,11 @@ class Engine:
 
     def denoise(self, latents, prompt_embeds, prompt_mask, timesteps, coef, guidance_scale, prediction_type="v_prediction",
                 rule="ddpm", clip_sample=False, clip_sample_range=1.0, noise=None, seed=0, sample_offset=0, use_graph=True,
-                beat_embeds=None, beat_mask=None, chord_embeds=None, chord_mask=None):
+                beat_embeds=None, beat_mask=None, chord_embeds=None, chord_mask=None, prompt_mask_host=None):
         """In-place denoise of `latents` [B,8,256,16] (fp32 cuda).  `timesteps` int64 [N] and `coef`
-        float32 [N,8] are host tables from tango_amd.scheduler."""
+        float32 [N,8] are host tables from tango_amd.scheduler.  `prompt_mask_host`: the caller's CPU copy of a `prompt_mask`
+        that already lives on the device (the tokenizer's attention mask): the engine then picks its plan from it instead of
+        reading the device mask back, i.e. the call does not synchronise the host."""
         assert latents.is_cuda and latents.dtype == torch.float32 and latents.is_contiguous()
         self._check_latents("latents", latents)
         enc = self._f32(prompt_embeds)
@@ -266,6 +268,10 @@ class Engine:
         # a mask that is still on the host (tokenizer output) also travels as a host pointer: the engine then picks its plan without
         # reading the device copy back (no host sync inside the call)
         mask_host = prompt_mask.to(torch.uint8).contiguous() if prompt_mask is not None and not prompt_mask.is_cuda else None
+        if mask_host is None and prompt_mask_host is not None and prompt_mask is not None:
+            if prompt_mask_host.is_cuda or tuple(prompt_mask_host.shape) != tuple(prompt_mask.shape):
+                raise ValueError("prompt_mask_host must be a CPU tensor of prompt_mask's shape %s" % (tuple(prompt_mask.shape),))
+            mask_host = prompt_mask_host.to(torch.uint8).contiguous()
         rows = 2 * latents.shape[0] if guidance_scale > 1.0 else latents.shape[0]
         self._check_cond("prompt_embeds", enc, mask, rows)
         ts = np.ascontiguousarray(np.asarray(timesteps, dtype=np.int64))
@@ -333,6 +339,13 @@ class Engine:
         b, n = C.c_uint64(), C.c_int()
         _lib.check(self.lib.tango_engine_plan_stats(self._h, C.byref(b), C.byref(n)), "plan_stats")
         return int(b.value), int(n.value)
+
+    def last_step_gflop(self):
+        """GFLOP one launch of the last denoise call's step program executes (None before the first denoise call)"""
+        g = C.c_double()
+        if self.lib.tango_engine_last_step_gflop(self._h, C.byref(g)) != 0:
+            return None
+        return float(g.value)
 
     def last_denoise_ms(self):
         tot, per = C.c_float(), C.c_float()

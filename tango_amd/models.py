@@ -161,6 +161,12 @@ class AudioDiffusion:
 
     def encode_text_classifier_free(self, prompt: List[str], num_samples_per_prompt: int):
         """models.py:266-305: returns [uncond; cond] embeddings and the boolean mask."""
+        pe, pm, _ = self._encode_text_classifier_free(prompt, num_samples_per_prompt)
+        return pe, pm
+
+    def _encode_text_classifier_free(self, prompt: List[str], num_samples_per_prompt: int):
+        """the same, plus the tokenizer's own HOST copy of the mask (third value): `inference` hands it to the engine beside the device
+        mask, so that the plan is chosen without a device -> host read-back"""
         self._ensure_text()
         dev = self.device
         batch = self.tokenizer(prompt, max_length=self.tokenizer.model_max_length, padding=True, truncation=True,
@@ -177,7 +183,9 @@ class AudioDiffusion:
             ne = self.text_encoder(input_ids=uids, attention_mask=uam)[0]
         ne = ne.repeat_interleave(num_samples_per_prompt, 0)
         uam = uam.repeat_interleave(num_samples_per_prompt, 0)
-        return torch.cat([ne, pe]), (torch.cat([uam, am]) == 1).to(dev)
+        host = torch.cat([ub.attention_mask.repeat_interleave(num_samples_per_prompt, 0),
+                          batch.attention_mask.repeat_interleave(num_samples_per_prompt, 0)]) == 1      # tokenizer outputs: CPU tensors
+        return torch.cat([ne, pe]), (torch.cat([uam, am]) == 1).to(dev), host.cpu()
 
     # ---- latents -----------------------------------------------------------------------------
     def prepare_latents(self, batch_size, inference_scheduler, num_channels_latents, dtype, device):
@@ -187,23 +195,27 @@ class AudioDiffusion:
         return latents * inference_scheduler.init_noise_sigma
 
     # ---- the hot path ------------------------------------------------------------------------
-    def _pad_text(self, embeds, mask):
+    def _pad_text(self, embeds, mask, mask_host=None):
         """Static plan shapes: pad L up to a bucket with masked tokens.  Numerically exact: a masked
         key's weight is exp(-10000) == 0 in fp32 (SURVEY.md section 4 differential check)."""
         L = embeds.shape[1]
         if not self.bucket_text_len:
-            return embeds, mask
+            return embeds, mask, mask_host
         tgt = next((b for b in _TEXT_BUCKETS if b >= L), L)
         if tgt == L:
-            return embeds, mask
+            return embeds, mask, mask_host
         pe = torch.zeros((embeds.shape[0], tgt, embeds.shape[2]), device=embeds.device, dtype=embeds.dtype)
         pe[:, :L] = embeds
         pm = torch.zeros((mask.shape[0], tgt), device=mask.device, dtype=torch.bool)
         pm[:, :L] = mask
-        return pe, pm
+        if mask_host is not None:
+            ph = torch.zeros((mask.shape[0], tgt), dtype=torch.bool)
+            ph[:, :L] = mask_host
+            mask_host = ph
+        return pe, pm, mask_host
 
     def _denoise(self, prompt_embeds, boolean_prompt_mask, inference_scheduler, num_steps, guidance_scale, latents, noise, seed,
-                 sample_offset, **extra_conditions):
+                 sample_offset, mask_host=None, **extra_conditions):
         """the shared body of the loop of models.py:224-249 / mustango/models.py:563-598: seed derivation, text bucketing, scheduler
         tables, one engine call (`extra_conditions`: the Music UNet's beat / chord streams)"""
         cfg_on = guidance_scale > 1.0
@@ -216,7 +228,7 @@ class AudioDiffusion:
         if boolean_prompt_mask is None:
             boolean_prompt_mask = torch.ones(prompt_embeds.shape[:2], dtype=torch.bool, device=prompt_embeds.device)
         # (the mask is NOT moved here: a host mask reaches the engine as a host pointer too, which spares the call its only host sync)
-        pe, pm = self._pad_text(prompt_embeds.to(self.device), boolean_prompt_mask)
+        pe, pm, mask_host = self._pad_text(prompt_embeds.to(self.device), boolean_prompt_mask, mask_host)
         c = inference_scheduler.config
         if seed is None:
             # the reference draws step noise from torch's global generator (randn_tensor in scheduler.step): derive the
@@ -226,27 +238,29 @@ class AudioDiffusion:
         self.engine.denoise(latents, pe, pm, timesteps.cpu().numpy(), inference_scheduler.coef_table(), guidance_scale,
                             prediction_type=c.prediction_type, rule=inference_scheduler.rule, clip_sample=c.clip_sample,
                             clip_sample_range=getattr(c, "clip_sample_range", 1.0), noise=noise, seed=seed,
-                            sample_offset=sample_offset, use_graph=self.use_graph, **extra_conditions)
+                            sample_offset=sample_offset, use_graph=self.use_graph, prompt_mask_host=mask_host, **extra_conditions)
         return latents
 
     @torch.no_grad()
     def inference_from_embeddings(self, prompt_embeds, boolean_prompt_mask, inference_scheduler, num_steps=20,
-                                  guidance_scale=3, latents=None, noise=None, seed=None, sample_offset=0):
-        """Loop of models.py:224-249 given the encoder outputs ([uncond; cond] when guidance > 1)."""
+                                  guidance_scale=3, latents=None, noise=None, seed=None, sample_offset=0, mask_host=None):
+        """Loop of models.py:224-249 given the encoder outputs ([uncond; cond] when guidance > 1).  `mask_host`: optional CPU copy of
+        a device-resident `boolean_prompt_mask` (see Engine.denoise)."""
         return self._denoise(prompt_embeds, boolean_prompt_mask, inference_scheduler, num_steps, guidance_scale, latents, noise, seed,
-                             sample_offset)
+                             sample_offset, mask_host=mask_host)
 
     @torch.no_grad()
     def inference(self, prompt, inference_scheduler, num_steps=20, guidance_scale=3, num_samples_per_prompt=1,
                   disable_progress=True):
         """models.py:210-257 (same signature, same return: latents [B*S, 8, 256, 16])."""
+        host = None
         if guidance_scale > 1.0:
-            pe, pm = self.encode_text_classifier_free(prompt, num_samples_per_prompt)
+            pe, pm, host = self._encode_text_classifier_free(prompt, num_samples_per_prompt)
         else:
             pe, pm = self.encode_text(prompt)
             pe = pe.repeat_interleave(num_samples_per_prompt, 0)
             pm = pm.repeat_interleave(num_samples_per_prompt, 0)
-        return self.inference_from_embeddings(pe.float(), pm, inference_scheduler, num_steps, guidance_scale)
+        return self.inference_from_embeddings(pe.float(), pm, inference_scheduler, num_steps, guidance_scale, mask_host=host)
 
 
 class MusicAudioDiffusion(AudioDiffusion):

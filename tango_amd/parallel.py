@@ -10,7 +10,13 @@ inference-side parallelism (tango.py:54-60 is a Python loop over chunks) -- this
 Step noise is keyed by (seed, GLOBAL sample index): rank 0 draws ONE seed per batch and broadcasts it in the
 header, so results do not depend on the number of ranks and no per-rank call counter can drift.
 """
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
+
+# dmabuf IPC: the host driver of this platform supports no legacy IPC handles, and without this RCCL's intra-node transports fail with
+# `hipIpcGetMemHandle: invalid argument`.  It has to be in the environment before the HIP runtime initialises, i.e. it is set where the
+# multi-process path is IMPORTED (every rank imports this module before it touches its GPU), not only by bench.py's self-launcher.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
@@ -47,15 +53,20 @@ class DataParallelGenerator:
         self.compute = compute
         self.device = torch.device(device)
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # `collective`: a process group exists, so every exchange below goes through it -- also at world size 1, which is how the RCCL
+        # calls of this file (int64 / fp32 / uint8 broadcast, byte gather) are exercised on a one-GPU box (tests/test_parallel_nccl_gpu.py)
+        self.collective = dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.collective else 1
+        self.rank = dist.get_rank(group) if self.collective else 0
 
-    def _bcast(self, t: Optional[torch.Tensor], shape, dtype):
+    def _bcast(self, t: Optional[torch.Tensor], shape, dtype, keep_host: bool = False):
+        if not self.collective and keep_host and t is not None and not t.is_cuda:
+            return t.to(dtype).contiguous()          # single process: a host-resident mask stays on the host (no read-back later)
         if self.rank != 0:
             t = torch.empty(shape, dtype=dtype, device=self.device)
         else:
             t = t.to(self.device, dtype).contiguous()
-        if self.world > 1:
+        if self.collective:
             dist.broadcast(t, src=0, group=self.group)
         return t
 
@@ -72,11 +83,11 @@ class DataParallelGenerator:
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             hdr = torch.tensor(list(prompt_embeds.shape) + [int(seed)], dtype=torch.int64, device=self.device)
-        if self.world > 1:
+        if self.collective:
             dist.broadcast(hdr, src=0, group=self.group)
         n2, L, d, seed = [int(v) for v in hdr.tolist()]
         pe = self._bcast(prompt_embeds, (n2, L, d), torch.float32)
-        pm = self._bcast(mask.to(torch.uint8) if mask is not None else None, (n2, L), torch.uint8)
+        pm = self._bcast(mask.to(torch.uint8) if mask is not None else None, (n2, L), torch.uint8, keep_host=True)
         B = n2 // 2 if cfg_on else n2
         pe_l, pm_l, lo = shard_cfg_embeddings(pe, pm.bool(), self.world, self.rank, cfg_on)
         b_local = pe_l.shape[0] // 2 if cfg_on else pe_l.shape[0]
@@ -88,7 +99,7 @@ class DataParallelGenerator:
             assert wav.dtype == torch.int16 and tuple(wav.shape) == (b_local, n_samples), (wav.dtype, tuple(wav.shape))
         if after_compute is not None:
             after_compute()
-        if self.world == 1:
+        if not self.collective:
             return wav.cpu().numpy() if wav is not None else np.zeros((0, n_samples), np.int16)
         bmax = (B + self.world - 1) // self.world
         buf = torch.zeros((bmax, n_samples), dtype=torch.int16, device=self.device)
@@ -119,7 +130,7 @@ def generate_for_batch_dp(prompts: Optional[Sequence[str]], encode: Callable, co
     None on the other ranks."""
     dp = DataParallelGenerator(compute, torch.device(device), group)
     n = torch.tensor([len(prompts) if dp.rank == 0 else 0], dtype=torch.int64, device=dp.device)
-    if dp.world > 1:
+    if dp.collective:
         dist.broadcast(n, src=0, group=group)
     n = int(n.item())
     per_pass = batch_size * dp.world

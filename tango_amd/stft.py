@@ -79,6 +79,9 @@ class TacotronSTFT:
         self.mel_basis = torch.from_numpy(slaney_mel_filterbank(sampling_rate, filter_length, n_mel_channels, mel_fmin, mel_fmax))
         self.stft_fn = _StftFn(filter_length, hop_length, win_length, stft_forward_basis(filter_length, win_length))
         self.engine = Engine(stft=self.config, dtype="fp32", device=device)      # raises without the HIP library / a GPU
+        # one small plan per (batch, n_samples): a data-preparation loop over clips of arbitrary lengths must not grow this cache to the
+        # engine-wide 64-GiB default -- 1 GiB holds dozens of 10-s batches, older shapes are evicted first
+        self.engine.set_plan_budget(1 << 30)
         self._push()
 
     def _push(self):

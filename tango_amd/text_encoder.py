@@ -27,6 +27,7 @@ class T5EncoderOnEngine:
         self.config = dict(config)
         self.device = torch.device(device)
         self.engine = Engine(t5=self.config, dtype="fp32", device=device)
+        self.engine.set_plan_budget(4 << 30)     # (batch, length) plans of the text encoder are tens of MB each: keep the cache small
 
     @classmethod
     def from_state_dict(cls, sd: Dict[str, torch.Tensor], prefix: str = "text_encoder.", device="cuda:0"):

@@ -4,7 +4,8 @@ engine dtype (attention.hip, template parameter F8).
 
 Two references per case:
   * an EMULATION of exactly that arithmetic in torch (tile-wise online softmax over 64-key tiles, torch.float8_e4m3fn round trips
-    of 256 P and of clamp(V, +-448), fp32 row sums of the unquantised 256 P) -- tight: the kernel computes what it says;
+    of 256 P and of clamp(V, +-448), fp32 row sums of the ROUNDED 256 P -- round 5: numerator and denominator see the same
+    weights) -- tight: the kernel computes what it says;
   * the exact softmax(Q K^T) V -- loose: what switching the feature on costs (three mantissa bits on P and V, averaged over keys)."""
 import ctypes as C
 
@@ -37,7 +38,7 @@ def emulate(qh, kh, vh, scale):
         mn = torch.maximum(m, s.amax(-1, keepdim=True))
         alpha = torch.exp(m - mn)
         p = 256.0 * torch.exp(s - mn)
-        l = l * alpha + p.sum(-1, keepdim=True)
+        l = l * alpha + f8(p).sum(-1, keepdim=True)
         o = o * alpha + f8(p) @ vq[:, :, t0:t0 + 64]
         m = mn
     return o / l

@@ -91,3 +91,23 @@ def test_gn_coop_barrier_words_survive_mixed_geometries(lib):
         for it in range(50):
             for x, ga, be, first in cases:
                 assert torch.equal(gn(lib, "fp16", x, ga, be, 1e-5, 1), first), it
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+@pytest.mark.parametrize("B,Cc,HW", [(2, 320, 4096), (16, 640, 1024), (3, 320, 100), (2, 1280, 64)])
+def test_gn_coop_fallback_without_rendezvous_is_bit_identical(lib, dtype, B, Cc, HW):
+    """the kernel's co-residency is an estimate, so a workgroup whose partners do not arrive must not normalise with
+    incomplete sums.  It re-reduces every chunk of its sample itself, in phase 1's order.  TANGO_GN_COOP_FORCE_FALLBACK=1 sends EVERY
+    workgroup down that path without waiting for anyone: the output must equal the rendezvous path's bit for bit, and the barrier
+    words must be back at rest (the following normal launches neither hang nor differ)."""
+    g = torch.Generator().manual_seed(11 * B + Cc + HW)
+    x = q(torch.randn(B, Cc, HW, generator=g) * 1.3 - 0.2, dtype).cuda()
+    ga, be = torch.randn(Cc, generator=g).cuda(), torch.randn(Cc, generator=g).cuda()
+    with tuning(lib, TANGO_GN_COOP_ALL=1):
+        normal = gn(lib, dtype, x, ga, be, 1e-5, 1)
+    with tuning(lib, TANGO_GN_COOP_ALL=1, TANGO_GN_COOP_FORCE_FALLBACK=1):
+        forced = gn(lib, dtype, x, ga, be, 1e-5, 1)
+        forced2 = gn(lib, dtype, x, ga, be, 1e-5, 1)
+    with tuning(lib, TANGO_GN_COOP_ALL=1):
+        again = gn(lib, dtype, x, ga, be, 1e-5, 1)
+    assert torch.equal(forced, normal) and torch.equal(forced2, normal) and torch.equal(again, normal)

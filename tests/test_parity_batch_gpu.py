@@ -243,3 +243,52 @@ def test_100_steps_fp16_engine_against_fp32_engine():
     err = (res["fp16"] - res["fp32"]).abs().max().item()
     print("100 DDPM steps (config 2's length) fp16 engine vs fp32 engine: latents max abs err %.3e (|ref| max %.2f)" % (err, res["fp32"].abs().max()))
     assert torch.isfinite(res["fp16"]).all() and err <= 1.0e-2
+
+
+# ---- round 5: the mel-VAE decoder and HiFi-GAN AT THE BENCHMARKED BATCH (VERDICT r4 weak #1 / next #1a) ------------------------------
+
+def _mel_psnr(a, b):
+    peak = float(b.max() - b.min())
+    mse = float(((a - b) ** 2).mean())
+    return 10.0 * torch.log10(torch.tensor(peak * peak / (mse + 1e-30))).item()
+
+
+# floors: fp32 from the reference's own tolerances; fp16 / bf16 <= 3x the values measured on MI355X (round 5)
+@pytest.mark.parametrize("dtype,mel_tol,lsb_frac,snr_floor", [("fp32", 1e-5, 0.999, 80.0), ("fp16", 1.0e-2, 0.0, 45.0), ("bf16", 6e-2, 0.0, 24.0)])
+def test_vae_and_vocoder_at_benchmarked_batch(dtype, mel_tol, lsb_frac, snr_floor):
+    """`decode_first_stage` (autoencoder.py:116-124) and `decode_to_waveform` (autoencoder.py:66-69, hifigan/utilities.py:76-86)
+    exactly as bench.py's timed region runs them: ONE engine call at B = 32 and at B = 8 (1.07-GB activations, the B-sized grids of
+    every VAE / vocoder kernel), end to end latents -> mel -> int16, rows {0, 15, 31} / {0, 3, 7} against the fp32 oracle at B = 1.
+    The B = 8 latents are the first 8 of the B = 32 ones, so the oracle rows are shared."""
+    import numpy as np
+    shapes = W.vae_decoder_param_shapes(O.VAE_CONFIG)
+    shapes.update(W.hifigan_param_shapes(O.HIFIGAN_CONFIG))
+    sd = W.synth_state_dict(shapes, 1234)
+    g = torch.Generator().manual_seed(3288)
+    z = torch.randn(BMAX, 8, 256, 16, generator=g) * 1.1          # latent std after a denoise loop (SURVEY.md 8c)
+    e = Engine(vae=O.VAE_CONFIG, hifigan=O.HIFIGAN_CONFIG, dtype=dtype)
+    e.load_synthetic(1234)
+    ref = {}
+    for B in (32, 8):
+        mel = e.vae_decode(z[:B].cuda())
+        wav = e.vocode(mel)
+        torch.cuda.synchronize()
+        mel, wav = mel.cpu(), wav.cpu().numpy()
+        assert mel.shape == (B, 1, 1024, 64) and wav.shape == (B, 163872) and wav.dtype == np.int16
+        assert torch.isfinite(mel).all()
+        for i in ROWS[B]:
+            if i not in ref:
+                with torch.no_grad():
+                    m = O.vae_decode_first_stage(sd, O.VAE_CONFIG, z[i:i + 1])
+                    ref[i] = (m, O.decode_to_waveform(sd, O.HIFIGAN_CONFIG, m))
+            mel_ref, wav_ref = ref[i]
+            merr = ((mel[i:i + 1] - mel_ref).abs().max() / mel_ref.abs().max()).item()
+            d = np.abs(wav[i].astype(np.int32) - wav_ref[0].astype(np.int32))
+            frac1 = float((d <= 1).mean())
+            snr = 10 * np.log10((wav_ref[0].astype(np.float64) ** 2).mean() / ((d.astype(np.float64) ** 2).mean() + 1e-9))
+            print("B=%d %s engine, sample %d: mel rel err %.3e (PSNR %.1f dB), int16 |diff| max %d, <=1 LSB on %.5f, wave SNR %.1f dB"
+                  % (B, dtype, i, merr, _mel_psnr(mel[i:i + 1], mel_ref), d.max(), frac1, snr))
+            assert merr <= mel_tol, (B, i, merr)
+            assert frac1 >= lsb_frac and snr >= snr_floor, (B, i, frac1, snr)
+        assert not np.array_equal(wav[1], wav[2])
+    del e
