@@ -287,6 +287,7 @@ int launch_xattn_permute_wq(int dtype, const void* W, const float* b, const floa
 // then y[r][c] = x[r][c] + cvec[r / rows_per][c] for the rows of those samples (= attn2(norm2(x)) + x when one key is unmasked)
 int launch_xattn_const(int dtype, const void* vt, int64_t ldvt, int C, const int* key0, const void* wo, int64_t ldwo, const float* bo,
                        float* cvec, int nb, hipStream_t s);
+int launch_copy_rows(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int C, hipStream_t s);   // strided row copy
 int launch_rowbias_add(int dtype, const void* x, int64_t ldx, const float* cvec, void* y, int64_t ldy, int64_t rows, int rows_per, int C,
                        hipStream_t s);
 

@@ -569,4 +569,26 @@ int launch_rowbias_add(int dtype, const void* x, int64_t ldx, const float* cvec,
   return 0;
 }
 
+// y[r][0..C) = x[r][0..C) for strided row views (16-byte pieces); engine dtype irrelevant beyond its size
+__global__ __launch_bounds__(256) void copy_rows_kernel(const unsigned char* __restrict__ x, int64_t ldx_b, unsigned char* __restrict__ y, int64_t ldy_b,
+                                                        int64_t rows, int pieces) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * pieces) return;
+  const int64_t r = idx / pieces;
+  const int pc = (int)(idx - r * pieces);
+  *(u32x4*)(y + r * ldy_b + (int64_t)pc * 16) = *(const u32x4*)(x + r * ldx_b + (int64_t)pc * 16);
+}
+int launch_copy_rows(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int C, hipStream_t s) {
+  if (rows <= 0) return 0;
+  const int esz = dtype == DT_F32 ? 4 : 2;
+  if ((C * esz) % 16 != 0 || (ldx * esz) % 16 != 0 || (ldy * esz) % 16 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15))
+    TANGO_FAIL("copy_rows: 16-byte alignment");
+  const int pieces = C * esz / 16;
+  const int64_t n = rows * pieces;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const unsigned char*)x, ldx * esz, (unsigned char*)y,
+                     ldy * esz, rows, pieces);
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace tango

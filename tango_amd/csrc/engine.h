@@ -142,6 +142,15 @@ struct UNetPlan {
   hipGraph_t graph_k = nullptr;
   hipGraphExec_t exec_k = nullptr;
   int k_steps = 0;
+  // Two independent chains (round 5; Engine::denoise): a "dual" plan owns only the UNet input / output buffers of the whole batch; its
+  // two children run the first and the second half of the samples (no op of the UNet crosses samples) as two branches of the captured
+  // graph, so that one branch's dispatch gaps and kernel tails are filled by the other's kernels.  A child takes xin / eps from its
+  // parent (ext_*), owns its slab and program, and is never in the plan map on its own (the parent's eviction frees all three slabs).
+  std::unique_ptr<UNetPlan> child[2];
+  void* ext_xin = nullptr;
+  float* ext_eps = nullptr;
+  bool cfg_shared = false;     // mode 3: the part of the UNet in front of the first cross-attention runs on B2 / 2 samples (build_unet)
+  unsigned* sync = nullptr;    // barrier words its cooperative kernels use (one set per chain: two chains may run such a kernel at once)
 };
 struct T5LayerW {          // T5Block of the encoder: self-attention + gated-GELU feed-forward (no biases anywhere)
   WNorm ln1, ln2;
@@ -298,12 +307,16 @@ class Engine {
   float* d_temb = nullptr;       // [max_steps][temb]  silu(emb)
   std::vector<int64_t> temb_ts;  // cache key
   int max_steps = 1000;
-  std::map<std::array<int, 5>, std::unique_ptr<UNetPlan>> unet_plans;   // key: (B2, L_text, L_beat, L_chord, n_short)
+  std::map<std::array<int, 6>, std::unique_ptr<UNetPlan>> unet_plans;   // key: (B2, L_text, L_beat, L_chord, n_short, chains)
   std::map<int, std::unique_ptr<VaePlan>> vae_plans;
   std::map<int, std::unique_ptr<VaePlan>> vae_enc_plans;
   std::map<std::pair<int, int>, std::unique_ptr<VaePlan>> voc_plans;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t cap_stream = nullptr;
+  // second chain of a dual plan: its capture stream, its eager stream, fork / join events (capture and eager pairs), barrier words
+  hipStream_t cap_stream2 = nullptr, aux_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork_e = nullptr, ev_join_e = nullptr;
+  unsigned* d_sync2 = nullptr;
   int last_steps = 0;
 
   // ---- host -> device staging without a host sync (round 4) ----
@@ -328,7 +341,11 @@ class Engine {
   void release_slab(char** slab, PlanMeta& m);
 
   int ensure_temb(const int64_t* ts_host, int n, hipStream_t s);
-  int get_unet_plan(int B2, int L, int Lbeat, int Lchord, int n_short, UNetPlan** out);
+  int get_unet_plan(int B2, int L, int Lbeat, int Lchord, int n_short, UNetPlan** out, int chains = 1);
+  int make_unet_plan(UNetPlan& P);            // measure, allocate the slab, build the programs
+  void free_unet_plan(UNetPlan& P);           // graphs, slab(s), children; gives the bytes back to the budget
+  bool cfg_shared_ok(int B2, int n_short) const;
+  int unet_chains_for(int B2) const;          // 1 or 2: how denoise() runs a batch of B2 UNet rows
   int single_key_prefix(const uint8_t* mask_dev, const uint8_t* mask_host, int B2, int L, std::vector<int>& key0, hipStream_t s);
   int build_unet(UNetPlan& P, Arena& A, bool record);
   int get_vae_plan(int B, VaePlan** out);

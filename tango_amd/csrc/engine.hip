@@ -56,6 +56,7 @@ struct Builder {
   bool record;
   int dt;
   size_t esz;
+  unsigned* sync = nullptr;   // barrier words for cooperative kernels (null: the engine's first set)
 
   TView alloc(int64_t rows, int C) {
     TView t;
@@ -184,7 +185,7 @@ struct Builder {
     GroupNormParams p;
     p.x = x.p; p.ldx = x.ld; p.y = out.p; p.ldy = out.ld; p.gamma = w.g; p.beta = w.b;
     p.B = B; p.rows = rows; p.C = w.C; p.groups = groups; p.eps = w.eps; p.act = act;
-    p.sync = E.d_sync;
+    p.sync = sync ? sync : E.d_sync;
     const size_t m = A.mark();
     const size_t nf = groupnorm_ws_floats(B, rows, w.C, groups);
     float* ws = alloc_f32(nf);
@@ -282,23 +283,31 @@ struct Builder {
   }
 
   // Transformer2DModel (transformer_2d.py:214-321) + BasicTransformerBlock (attention.py:276-335)
+  // `shared` (round 5): the CFG batch [uncond; cond] enters with IDENTICAL rows in both halves (models.py:233: `torch.cat([latents] * 2)`,
+  // same timestep) and nothing before the first cross-attention looks at the text, so x holds only B / 2 samples and
+  // norm -> proj_in -> norm1 -> q | k | v -> self-attention -> to_out run ONCE; the halves part ways at attn2 (unconditional rows: the
+  // single-key constant; conditional rows: the text) and everything from there on works on all B samples.  Exact: the same kernels
+  // would have produced the same values twice.  Requires nshort == B / 2 (the CFG structure) -- the caller checks.
   void transformer(const XfW& w, const TView& x, int B, int H, int W, int groups, const TView& kv, const void* kvt,
-                   const float* bias, int L, const TView& out, int nshort = 0, const float* cvec = nullptr) {
+                   const float* bias, int L, const TView& out, int nshort = 0, const float* cvec = nullptr, bool shared = false) {
     const int C = w.C, HW = H * W;
     const int64_t rows = (int64_t)B * HW;
+    const int Bp = shared ? B / 2 : B;                  // samples of the part in front of attn2
+    const int64_t rows_p = (int64_t)Bp * HW;
     const size_t m = A.mark();
-    TView t0 = alloc(rows, C);
-    groupnorm(x, B, HW, w.gn, groups, ACT_NONE, t0);
+    auto rows_from = [&](const TView& v, int64_t r0) { TView t = v; t.p = (char*)v.p + (size_t)r0 * v.ld * esz; return t; };
+    TView t0 = alloc(rows_p, C);
+    groupnorm(x, Bp, HW, w.gn, groups, ACT_NONE, t0);
     TView h = alloc(rows, C);
-    linear(t0, rows, w.proj_in, h);
-    TView qkv = alloc(rows, 2 * C);                 // [q | k]; v goes transposed into vt [B][C][HW]
-    void* vt = A.alloc((size_t)rows * C * esz);
+    linear(t0, rows_p, w.proj_in, h);
+    TView qkv = alloc(rows_p, 2 * C);               // [q | k]; v goes transposed into vt [B][C][HW]
+    void* vt = A.alloc((size_t)rows_p * C * esz);
     GOpt nb; nb.use_bias = false;
-    { GOpt o = nb; o.ln = &w.ln1; o.vt = vt; o.vt_n0 = 2 * C; o.vt_S = HW; o.vt_ld = HW; linear(h, rows, w.qkv, qkv, o); }
-    TView a = alloc(rows, C);
+    { GOpt o = nb; o.ln = &w.ln1; o.vt = vt; o.vt_n0 = 2 * C; o.vt_S = HW; o.vt_ld = HW; linear(h, rows_p, w.qkv, qkv, o); }
+    TView a = alloc(rows_p, C);
     // self-attention; `unet_attn_fp8` (BASELINE config 5): P.V on the fp8 MFMA at the sites that dominate the attention time
     // (unmasked, Skv a multiple of 64); cross-attention (64 text tokens, masked) stays in the engine dtype
-    attention(slice(qkv, 0, C, esz), slice(qkv, C, C, esz), vt, HW, a, nullptr, B, w.heads, HW, HW, 0.125f, nullptr,
+    attention(slice(qkv, 0, C, esz), slice(qkv, C, C, esz), vt, HW, a, nullptr, Bp, w.heads, HW, HW, 0.125f, nullptr,
               E.cfg.unet_attn_fp8 != 0 && dt != DT_F32 && HW % 64 == 0);
     TView h1 = alloc(rows, C);
     TView h2 = h;                       // h is dead after h1 was produced
@@ -307,23 +316,31 @@ struct Builder {
     // constant (elementwise.hip: xattn_const / rowbias_add); the cross-attention proper runs on the remaining samples only.
     const int ns = cvec ? nshort : 0;
     const int64_t rs = (int64_t)ns * HW, rc = rows - rs;
-    auto rows_from = [&](const TView& v, int64_t r0) { TView t = v; t.p = (char*)v.p + (size_t)r0 * v.ld * esz; return t; };
     // attn1's to_out + residual; where its kernel can, the single-key rows get their constant in the same epilogue and land in h2
     // directly (in place over the residual h: every element is read and written by the same lane) -- no separate pass over them
     bool fused_const = false;
-    {
+    if (shared) {
+      // one to_out for both halves into the FIRST half of h1 (h1s); the unconditional rows of h2 = h1s + constant (a pass that reads
+      // h1s and writes h2's first half -- h's first half, the to_out residual, is dead by then); the conditional rows read h1s as well
+      GOpt o; o.residual = &h;
+      linear(a, rows_p, w.o1, h1, o);
+      const int d = dt, hw = HW, c = C;
+      const void* xs = h1.p; void* ys = h2.p; const int64_t lx = h1.ld, ly = h2.ld;
+      push([=](hipStream_t s) { return launch_rowbias_add(d, xs, lx, cvec, ys, ly, rs, hw, c, s); },
+           "xattn_single_key rows=" + std::to_string(rs) + " C=" + std::to_string(C));
+    } else {
       GOpt o; o.residual = &h;
       if (ns > 0) { o.rowvec = cvec; o.rowvec_rows = rs; o.rowvec_per = HW; o.out_lo = &h2; o.rowvec_done = &fused_const; }
       linear(a, rows, w.o1, h1, o);
     }
-    if (ns > 0 && !fused_const) {
+    if (!shared && ns > 0 && !fused_const) {
       const int d = dt, hw = HW, c = C;
       const void* xs = h1.p; void* ys = h2.p; const int64_t lx = h1.ld, ly = h2.ld;
       push([=](hipStream_t s) { return launch_rowbias_add(d, xs, lx, cvec, ys, ly, rs, hw, c, s); },
            "xattn_single_key rows=" + std::to_string(rs) + " C=" + std::to_string(C));
     }
     if (rc > 0) {
-      const TView h1c = rows_from(h1, rs), h2c = rows_from(h2, rs), kvc = rows_from(kv, (int64_t)ns * L);
+      const TView h1c = shared ? h1 : rows_from(h1, rs), h2c = rows_from(h2, rs), kvc = rows_from(kv, (int64_t)ns * L);
       const void* kvtc = (const char*)kvt + (size_t)ns * C * Lp8 * esz;
       const float* biasc = bias ? bias + (int64_t)ns * L : nullptr;
       const int Bc = B - ns;
@@ -349,7 +366,14 @@ struct Builder {
     { GOpt o; o.epi = EPI_GEGLU; o.ln = &w.ln3; linear(h2, rows, w.ff1, gg, o); }
     TView h3 = h1;                      // h1 is dead after h2 was produced
     { GOpt o; o.residual = &h2; linear(gg, rows, w.ff2, h3, o); }
-    { GOpt o; o.residual = &x; linear(h3, rows, w.proj_out, out, o); }
+    if (shared) {
+      // the residual x exists once (B / 2 samples): one launch per half, both reading it
+      GOpt o; o.residual = &x;
+      linear(h3, rows_p, w.proj_out, out, o);
+      linear(rows_from(h3, rows_p), rows_p, w.proj_out, rows_from(out, rows_p), o);
+    } else {
+      GOpt o; o.residual = &x; linear(h3, rows, w.proj_out, out, o);
+    }
     A.release(m);
   }
 };
@@ -364,13 +388,7 @@ Engine::Engine(const tango_config_t& c) : cfg(c) {
 
 Engine::~Engine() {
   (void)hipDeviceSynchronize();     // replays of the graphs destroyed below may still be in flight (denoise does not wait for its stream)
-  for (auto& kv : unet_plans) {
-    if (kv.second->exec) (void)hipGraphExecDestroy(kv.second->exec);
-    if (kv.second->graph) (void)hipGraphDestroy(kv.second->graph);
-    if (kv.second->exec_k) (void)hipGraphExecDestroy(kv.second->exec_k);
-    if (kv.second->graph_k) (void)hipGraphDestroy(kv.second->graph_k);
-    if (kv.second->slab) (void)hipFree(kv.second->slab);
-  }
+  for (auto& kv : unet_plans) free_unet_plan(*kv.second);
   for (auto& kv : vae_plans) if (kv.second->slab) (void)hipFree(kv.second->slab);
   for (auto& kv : vae_enc_plans) if (kv.second->slab) (void)hipFree(kv.second->slab);
   for (auto& kv : voc_plans) if (kv.second->slab) (void)hipFree(kv.second->slab);
@@ -382,6 +400,9 @@ Engine::~Engine() {
     if (hs.buf) (void)hipHostFree(hs.buf);
   }
   if (cap_stream) (void)hipStreamDestroy(cap_stream);
+  if (cap_stream2) (void)hipStreamDestroy(cap_stream2);
+  if (aux_stream) (void)hipStreamDestroy(aux_stream);
+  for (hipEvent_t e : {ev_fork, ev_join, ev_fork_e, ev_join_e}) if (e) (void)hipEventDestroy(e);
   if (ev0) (void)hipEventDestroy(ev0);
   if (ev1) (void)hipEventDestroy(ev1);
 }
@@ -455,13 +476,9 @@ bool Engine::evict_lru() {
     case 0:
       return lru_erase(unet_plans, best, [&](UNetPlan& P) {
         //  a replay of this plan may still be in flight -- denoise() no longer waits for its stream, and destroying an
-        // executing graph is not safe on HIP: drain the device first (hipFree below would do so anyway, but only AFTER the destroy)
+        // executing graph is not safe on HIP: drain the device first (hipFree would do so anyway, but only AFTER the destroy)
         (void)hipDeviceSynchronize();
-        if (P.exec) (void)hipGraphExecDestroy(P.exec);
-        if (P.graph) (void)hipGraphDestroy(P.graph);
-        if (P.exec_k) (void)hipGraphExecDestroy(P.exec_k);
-        if (P.graph_k) (void)hipGraphDestroy(P.graph_k);
-        drop(P);
+        free_unet_plan(P);
       });
     case 1: return lru_erase(vae_plans, best, [&](VaePlan& P) { drop(P); });
     case 2: return lru_erase(vae_enc_plans, best, [&](VaePlan& P) { drop(P); });
@@ -469,6 +486,16 @@ bool Engine::evict_lru() {
     case 4: return lru_erase(t5_plans, best, [&](T5Plan& P) { drop(P); });
     default: return lru_erase(stft_plans, best, [&](StftPlan& P) { drop(P); });
   }
+}
+
+void Engine::free_unet_plan(UNetPlan& P) {
+  if (P.exec) (void)hipGraphExecDestroy(P.exec);
+  if (P.graph) (void)hipGraphDestroy(P.graph);
+  if (P.exec_k) (void)hipGraphExecDestroy(P.exec_k);
+  if (P.graph_k) (void)hipGraphDestroy(P.graph_k);
+  P.exec = P.exec_k = nullptr; P.graph = P.graph_k = nullptr;
+  for (auto& c : P.child) if (c) { free_unet_plan(*c); c.reset(); }
+  release_slab(&P.slab, P.meta);
 }
 
 int Engine::make_room(size_t need) {
@@ -891,6 +918,9 @@ int Engine::init() {
   d_sync = (unsigned*)dmalloc((size_t)coop_sync_words() * 4);
   if (!d_sync) return -1;
   TANGO_HIP(hipMemset(d_sync, 0, (size_t)coop_sync_words() * 4));
+  d_sync2 = (unsigned*)dmalloc((size_t)coop_sync_words() * 4);
+  if (!d_sync2) return -1;
+  TANGO_HIP(hipMemset(d_sync2, 0, (size_t)coop_sync_words() * 4));
   if (cfg.unet_levels > 0) {
     for (int i = 0; i < cfg.unet_levels; ++i)
       if (cfg.unet_channels[i] != cfg.unet_heads[i] * 64) TANGO_FAIL("engine: UNet channels must equal heads * 64 (head_dim 64)");
@@ -1014,7 +1044,7 @@ int Engine::ensure_temb(const int64_t* ts_host, int n, hipStream_t s) {
 // UNet plan
 // ================================================================================================
 int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
-  Builder b{*this, A, &P.step, record, dt, esz};
+  Builder b{*this, A, &P.step, record, dt, esz, P.sync};
   const int nl = cfg.unet_levels;
   const int* ch = cfg.unet_channels;
   const int B2 = P.B2, G = cfg.unet_groups;
@@ -1025,9 +1055,15 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
   const int cin_pad = 8 > cfg.unet_in_channels ? 8 : ((cfg.unet_in_channels + 7) / 8) * 8;
 
   // ---- persistent buffers ----
-  TView xin = b.alloc(rows_at(0), cin_pad);
+  TView xin;
+  if (P.ext_xin) {                       // a chain of a dual plan: the parent owns the whole batch's input / output buffers
+    xin.p = P.ext_xin; xin.ld = cin_pad; xin.C = cin_pad;
+    P.eps = P.ext_eps;
+  } else {
+    xin = b.alloc(rows_at(0), cin_pad);
+    P.eps = (float*)A.alloc((size_t)rows_at(0) * cfg.unet_out_channels * 4);
+  }
   P.xin = xin.p;
-  P.eps = (float*)A.alloc((size_t)rows_at(0) * cfg.unet_out_channels * 4);
   const int ncond = cfg.unet_music ? 3 : 1;
   TView encv[3];
   for (int c = 0; c < ncond; ++c) {
@@ -1090,10 +1126,10 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
     }
   }
   // one cross-attention site: `attentions[j]`, then (Music UNet) `attentions2[j]` on the beats and `attentions3[j]` on the chords
-  auto xf_site = [&](const XfW& w1, const XfW* w2, const XfW* w3, const TView& x, int lvl, const TView& out) {
+  auto xf_site = [&](const XfW& w1, const XfW* w2, const XfW* w3, const TView& x, int lvl, const TView& out, bool shared = false) {
     auto one = [&](const XfW& w, const TView& in, const TView& o) {
       const size_t k = kv_idx(&w);
-      b.transformer(w, in, B2, HH(lvl), WW(lvl), G, kvs[k], kvts[k], P.biases[w.cond], P.Lc[w.cond], o, w.cond == 0 ? P.n_short : 0, cvecs[k]);
+      b.transformer(w, in, B2, HH(lvl), WW(lvl), G, kvs[k], kvts[k], P.biases[w.cond], P.Lc[w.cond], o, w.cond == 0 ? P.n_short : 0, cvecs[k], shared);
     };
     if (!w2) { one(w1, x, out); return; }
     const size_t m = A.mark();
@@ -1112,12 +1148,29 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
   };
 
   // ---- down path ----
+  // CFG-shared prefix (round 5; Builder::transformer `shared`): the batch is [uncond; cond] with identical latents in both halves, so
+  // conv_in, the first ResBlock and the first transformer up to its cross-attention are computed for B2 / 2 samples only.  conv_in's
+  // output is also skip 0 -- the last up-block ResBlock reads it for all B2 samples -- so its second half is filled by a row copy.
+  const bool shared = P.cfg_shared;
+  const int Bh = B2 / 2;
   TView h = skip_dst();                                    // conv_in output = skip 0
-  b.conv3x3(xin, B2, HH(0), WW(0), HH(0), WW(0), 1, 0, conv_in, h);
+  b.conv3x3(xin, shared ? Bh : B2, HH(0), WW(0), HH(0), WW(0), 1, 0, conv_in, h);
+  if (shared) {
+    const int d = dt, c = ch[0];
+    const int64_t rh = rows_at(0) / 2, ld = h.ld;
+    const void* src = h.p; void* dst = (char*)h.p + (size_t)rh * ld * esz;
+    b.push([=](hipStream_t s) { return launch_copy_rows(d, src, ld, dst, ld, rh, c, s); }, "copy skip0 rows=" + std::to_string(rh));
+  }
   for (int i = 0; i < nl; ++i) {
     for (int j = 0; j < lpb; ++j) {
       const bool xa = !down[i].xf.empty();
-      if (xa) {
+      if (xa && shared && i == 0 && j == 0) {
+        TView r = b.alloc(rows_at(0) / 2, ch[0]);
+        b.resblock(down[0].res[0], h, Bh, HH(0), WW(0), G, r);
+        TView o = skip_dst();
+        xf_site(down[0].xf[0], nullptr, nullptr, r, 0, o, true);
+        h = o;
+      } else if (xa) {
         TView r = b.alloc(rows_at(i), ch[i]);
         b.resblock(down[i].res[j], h, B2, HH(i), WW(i), G, r);
         TView o = skip_dst();
@@ -1185,23 +1238,53 @@ int Engine::build_unet(UNetPlan& P, Arena& A, bool record) {
   return 0;
 }
 
-int Engine::get_unet_plan(int B2, int L, int Lbeat, int Lchord, int n_short, UNetPlan** out) {
+int Engine::make_unet_plan(UNetPlan& P) {
+  Arena m;
+  TANGO_TRY(build_unet(P, m, false));
+  TANGO_TRY(alloc_slab(&P.slab, m.peak + 256, P.meta, true));   // zero-filled: V^T pad columns (L not a multiple of 8) must stay zero
+  Arena a; a.base = P.slab;
+  P.pre.ops.clear(); P.step.ops.clear(); P.pre.labels.clear(); P.step.labels.clear(); P.pre.flops.clear(); P.step.flops.clear();
+  if (int rc = build_unet(P, a, true)) { release_slab(&P.slab, P.meta); return rc; }
+  return 0;
+}
+
+int Engine::get_unet_plan(int B2, int L, int Lbeat, int Lchord, int n_short, UNetPlan** out, int chains) {
   if (cfg.unet_music && (Lbeat <= 0 || Lchord <= 0)) TANGO_FAIL("engine: the Music UNet needs beat and chord conditions (beat_len, chord_len > 0)");
   if (!cfg.unet_music) { Lbeat = 0; Lchord = 0; }
   if (n_short < 0 || n_short > B2) TANGO_FAIL("engine: bad single-key prefix");
-  const std::array<int, 5> key = {B2, L, Lbeat, Lchord, n_short};
+  // `chains` doubles as the plan's mode: 1 one program for the whole batch, 2 two half-batch chains, 3 one program with the CFG-shared prefix
+  if (chains != 1 && ((chains != 2 && chains != 3) || B2 % 2 != 0)) TANGO_FAIL("engine: dual / CFG-shared plans need an even batch");
+  if (chains == 3 && !cfg_shared_ok(B2, n_short)) TANGO_FAIL("engine: the CFG-shared prefix needs a [single-key; text] batch and a plain UNet");
+  const std::array<int, 6> key = {B2, L, Lbeat, Lchord, n_short, chains};
   auto it = unet_plans.find(key);
   if (it != unet_plans.end()) { touch(it->second->meta); *out = it->second.get(); return 0; }
   if (!finalized) TANGO_FAIL("engine: weights not finalized");
   std::unique_ptr<UNetPlan> P(new UNetPlan());
   P->B2 = B2; P->L = L; P->n_short = n_short;
   P->Lc[0] = L; P->Lc[1] = Lbeat; P->Lc[2] = Lchord;
-  Arena m;
-  TANGO_TRY(build_unet(*P, m, false));
-  TANGO_TRY(alloc_slab(&P->slab, m.peak + 256, P->meta, true));   // zero-filled: V^T pad columns (L not a multiple of 8) must stay zero
-  Arena a; a.base = P->slab;
-  P->pre.ops.clear(); P->step.ops.clear(); P->pre.labels.clear(); P->step.labels.clear(); P->pre.flops.clear(); P->step.flops.clear();
-  if (int rc = build_unet(*P, a, true)) { release_slab(&P->slab, P->meta); return rc; }
+  if (chains == 1 || chains == 3) {
+    P->cfg_shared = chains == 3;
+    TANGO_TRY(make_unet_plan(*P));
+  } else {
+    // the parent: input and output of the whole batch (what the scheduler kernel reads and writes), nothing else
+    const int HW = cfg.latent_h * cfg.latent_w, hb = B2 / 2;
+    const int cin_pad = 8 > cfg.unet_in_channels ? 8 : ((cfg.unet_in_channels + 7) / 8) * 8;
+    const size_t xin_bytes = ((size_t)B2 * HW * cin_pad * esz + 255) & ~(size_t)255, eps_bytes = (size_t)B2 * HW * cfg.unet_out_channels * 4;
+    TANGO_TRY(alloc_slab(&P->slab, xin_bytes + eps_bytes + 256, P->meta, true));
+    P->xin = P->slab;
+    P->eps = (float*)(P->slab + xin_bytes);
+    for (int k = 0; k < 2; ++k) {
+      std::unique_ptr<UNetPlan> C(new UNetPlan());
+      C->B2 = hb; C->L = L;
+      C->Lc[0] = L; C->Lc[1] = Lbeat; C->Lc[2] = Lchord;
+      C->n_short = k == 0 ? (n_short < hb ? n_short : hb) : (n_short > hb ? n_short - hb : 0);
+      C->ext_xin = (char*)P->xin + (size_t)k * hb * HW * cin_pad * esz;
+      C->ext_eps = P->eps + (size_t)k * hb * HW * cfg.unet_out_channels;
+      C->sync = k == 0 ? d_sync : d_sync2;
+      if (int rc = make_unet_plan(*C)) { free_unet_plan(*P); return rc; }
+      P->child[k] = std::move(C);
+    }
+  }
   *out = P.get();
   unet_plans[key] = std::move(P);
   return 0;
@@ -1268,6 +1351,24 @@ int Engine::unet_forward(const float* sample, int64_t t, const Cond (&c)[3], flo
 // steps per captured graph when TANGO_GRAPH_STEPS is unset (measured, round 5: see DESIGN.md section 5)
 static int graph_steps_default(int B2) { (void)B2; return 1; }
 
+// One chain or two (round 5)?  Two: the first and the second half of the UNet batch (with guidance: the unconditional and the
+// conditional rows) run as two independent kernel sequences -- two branches of the captured graph -- whose dispatch gaps and kernel
+// tails fill each other.  TANGO_UNET_CHAINS = 1 / 2 forces; unset = the measured rule.
+// May a guidance batch of B2 UNet rows whose first n_short rows are single-key run with the CFG-shared prefix (build_unet)?  The rows
+// b and B2 / 2 + b must carry identical latents -- true inside denoise() with guidance, which fills both halves from one tensor --, the
+// first half must be the single-key (unconditional) half, and the first down block must be a plain cross-attention block.
+bool Engine::cfg_shared_ok(int B2, int n_short) const {
+  return !tuning().no_cfg_shared && B2 >= 2 && B2 % 2 == 0 && n_short == B2 / 2 && !cfg.unet_music && cfg.unet_levels > 0 &&
+         cfg.unet_cross_attn[0] != 0 && cfg.unet_layers_per_block >= 1;
+}
+
+int Engine::unet_chains_for(int B2) const {
+  if (B2 < 2 || B2 % 2 != 0) return 1;
+  const int t = tuning().unet_chains;
+  if (t == 1 || t == 2) return t;
+  return 1;
+}
+
 int Engine::denoise(const tango_denoise_args_t& a, hipStream_t s) {
   if (a.num_steps <= 0) TANGO_FAIL("denoise: num_steps must be positive");
   const bool cfg_on = a.guidance_scale > 1.0f;
@@ -1275,7 +1376,11 @@ int Engine::denoise(const tango_denoise_args_t& a, hipStream_t s) {
   UNetPlan* P;
   std::vector<int> key0;
   const int ns = single_key_prefix(a.prompt_mask, a.prompt_mask_host, B2, a.text_len, key0, s);
-  TANGO_TRY(get_unet_plan(B2, a.text_len, a.beat_len, a.chord_len, ns, &P));
+  int chains = unet_chains_for(B2);
+  if (chains == 1 && cfg_on && cfg_shared_ok(B2, ns)) chains = 3;      // one program, CFG-shared prefix (mode 3 of get_unet_plan)
+  TANGO_TRY(get_unet_plan(B2, a.text_len, a.beat_len, a.chord_len, ns, &P, chains));
+  UNetPlan* const CA = chains == 2 ? P->child[0].get() : nullptr;
+  UNetPlan* const CB = chains == 2 ? P->child[1].get() : nullptr;
   TANGO_TRY(ensure_temb(a.timesteps, a.num_steps, s));
   const int HW = cfg.latent_h * cfg.latent_w;
   const int C = cfg.unet_in_channels;
@@ -1296,31 +1401,67 @@ int Engine::denoise(const tango_denoise_args_t& a, hipStream_t s) {
     c[0].emb = a.prompt_embeds; c[0].mask = a.prompt_mask; c[0].len = a.text_len;
     c[1].emb = a.beat_embeds; c[1].mask = a.beat_mask; c[1].len = a.beat_len;
     c[2].emb = a.chord_embeds; c[2].mask = a.chord_mask; c[2].len = a.chord_len;
-    TANGO_TRY(bind_text(*P, c, key0, s));
+    if (chains != 2) {
+      TANGO_TRY(bind_text(*P, c, key0, s));
+    } else {
+      // each chain binds its own half of the conditions (rows [0, B2/2) and [B2/2, B2) of every [B2, L, d] tensor)
+      const int hb = B2 / 2;
+      for (int k = 0; k < 2; ++k) {
+        UNetPlan& Ck = *P->child[k];
+        Cond ck[3];
+        for (int i = 0; i < 3; ++i) {
+          ck[i] = c[i];
+          if (c[i].emb) ck[i].emb = c[i].emb + (size_t)k * hb * c[i].len * cfg.unet_cross_dim;
+          if (c[i].mask) ck[i].mask = c[i].mask + (size_t)k * hb * c[i].len;
+          ck[i].mask_host = nullptr;
+        }
+        std::vector<int> k0;
+        if (Ck.n_short > 0) k0.assign(key0.begin() + (size_t)k * hb, key0.begin() + (size_t)k * hb + Ck.n_short);
+        TANGO_TRY(bind_text(Ck, ck, k0, s));
+      }
+    }
   }
   TANGO_TRY(launch_fill_zero(P->xin, (size_t)B2 * HW * 8 * esz, s));
   TANGO_TRY(launch_nchw_to_nhwc(dt, a.latents, P->xin, 8, B, C, HW, cfg_on ? 2 : 1, 1.0f, s));
 
+  if (chains == 2 && !ev_fork) {
+    TANGO_HIP(hipStreamCreateWithFlags(&cap_stream2, hipStreamNonBlocking));
+    TANGO_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&ev_fork, &ev_join, &ev_fork_e, &ev_join_e}) TANGO_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  }
   // one denoise step = UNet forward, fused CFG combine + scheduler update (writes the next UNet input), step counter++
-  auto run_step = [&](hipStream_t st) -> int {
-    TANGO_TRY(P->step.run(st));
+  // (two chains: fork after the previous step's update, join before this step's)
+  auto run_step = [&](hipStream_t st, hipStream_t st2, hipEvent_t ef, hipEvent_t ej) -> int {
+    if (chains != 2) {
+      TANGO_TRY(P->step.run(st));
+    } else {
+      TANGO_HIP(hipEventRecord(ef, st));
+      TANGO_HIP(hipStreamWaitEvent(st2, ef, 0));
+      TANGO_TRY(CA->step.run(st));
+      TANGO_TRY(CB->step.run(st2));
+      TANGO_HIP(hipEventRecord(ej, st2));
+      TANGO_HIP(hipStreamWaitEvent(st, ej, 0));
+    }
     TANGO_TRY(launch_sched_step(dt, d_sched, B2 * HW, st));
     return launch_step_inc(d_step, st);
   };
-  if (a.use_graph && !P->exec) {
-    // capture the whole step once per (B2, L) plan; every per-step quantity is read through d_step / d_sched
-    // (captured on an engine-owned stream: the caller's stream may be the legacy null stream,
-    // which cannot be captured; the instantiated graph is then launched on the caller's stream)
+  // capture `n` steps once per plan; every per-step quantity is read through d_step / d_sched
+  // (captured on an engine-owned stream: the caller's stream may be the legacy null stream,
+  // which cannot be captured; the instantiated graph is then launched on the caller's stream)
+  auto capture = [&](int n, hipGraph_t* g_out, hipGraphExec_t* x_out) -> int {
     if (!cap_stream) TANGO_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     TANGO_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeRelaxed));
-    int rc = run_step(cap_stream);
+    int rc = 0;
+    for (int i = 0; i < n && rc == 0; ++i) rc = run_step(cap_stream, cap_stream2, ev_fork, ev_join);
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(cap_stream, &g);
     if (rc != 0) return rc;
     if (e != hipSuccess) TANGO_FAIL(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    P->graph = g;
-    TANGO_HIP(hipGraphInstantiate(&P->exec, g, nullptr, nullptr, 0));
-  }
+    *g_out = g;
+    TANGO_HIP(hipGraphInstantiate(x_out, g, nullptr, nullptr, 0));
+    return 0;
+  };
+  if (a.use_graph && !P->exec) TANGO_TRY(capture(1, &P->graph, &P->exec));
   // k steps per replay (round 5; north_star: "the 100-200 denoise steps captured as a hipGraph"): the same kernel sequence captured k
   // times back to back -- every per-step quantity is read through the device-side step counter, so a k-step graph is just k copies.
   // What it removes is the host-side launch of every replay and the gap between two replays, which only shows at small batches
@@ -1329,16 +1470,7 @@ int Engine::denoise(const tango_denoise_args_t& a, hipStream_t s) {
   if (kk > a.num_steps) kk = a.num_steps;
   if (a.use_graph && kk > 1 && (!P->exec_k || P->k_steps != kk)) {
     if (P->exec_k) { TANGO_HIP(hipStreamSynchronize(s)); (void)hipGraphExecDestroy(P->exec_k); (void)hipGraphDestroy(P->graph_k); P->exec_k = nullptr; P->graph_k = nullptr; }
-    if (!cap_stream) TANGO_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
-    TANGO_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeRelaxed));
-    int rc = 0;
-    for (int i = 0; i < kk && rc == 0; ++i) rc = run_step(cap_stream);
-    hipGraph_t g = nullptr;
-    hipError_t e = hipStreamEndCapture(cap_stream, &g);
-    if (rc != 0) return rc;
-    if (e != hipSuccess) TANGO_FAIL(std::string("hipStreamEndCapture (k-step graph): ") + hipGetErrorString(e));
-    P->graph_k = g;
-    TANGO_HIP(hipGraphInstantiate(&P->exec_k, g, nullptr, nullptr, 0));
+    TANGO_TRY(capture(kk, &P->graph_k, &P->exec_k));
     P->k_steps = kk;
   }
   TANGO_HIP(hipEventRecord(ev0, s));
@@ -1348,13 +1480,14 @@ int Engine::denoise(const tango_denoise_args_t& a, hipStream_t s) {
       for (; i + kk <= a.num_steps; i += kk) TANGO_HIP(hipGraphLaunch(P->exec_k, s));
     for (; i < a.num_steps; ++i) {
       if (a.use_graph) TANGO_HIP(hipGraphLaunch(P->exec, s));
-      else TANGO_TRY(run_step(s));
+      else TANGO_TRY(run_step(s, aux_stream, ev_fork_e, ev_join_e));
     }
   }
   TANGO_HIP(hipEventRecord(ev1, s));
   last_steps = a.num_steps;
   last_step_gflop = 0.0;
-  for (double f : P->step.flops) last_step_gflop += f / 1e9;
+  for (const UNetPlan* q : {chains != 2 ? (const UNetPlan*)P : (const UNetPlan*)CA, (const UNetPlan*)CB})
+    if (q) for (double f : q->step.flops) last_step_gflop += f / 1e9;
   return 0;
 }
 
@@ -1382,7 +1515,8 @@ int Engine::profile_unet(int B2, int L, std::string& report, hipStream_t s) {
   UNetPlan* P;
   // the product's CFG structure: the first half of the batch is the unconditional (single-key) half
   const int ns = (!tuning().no_single_key && B2 % 2 == 0) ? B2 / 2 : 0;
-  TANGO_TRY(get_unet_plan(B2, L, cfg.unet_music ? 50 : 0, cfg.unet_music ? 20 : 0, ns, &P));   // mustango/models.py:336,340: beat_len 50, chord_len 20
+  // (and the plan denoise() would run for it: with the CFG-shared prefix where that applies)
+  TANGO_TRY(get_unet_plan(B2, L, cfg.unet_music ? 50 : 0, cfg.unet_music ? 20 : 0, ns, &P, cfg_shared_ok(B2, ns) ? 3 : 1));   // mustango/models.py:336,340: beat_len 50, chord_len 20
   int64_t t = 500;
   TANGO_TRY(ensure_temb(&t, 1, s));
   TANGO_HIP(hipMemsetAsync(d_step, 0, 4, s));
