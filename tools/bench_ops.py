@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Micro-benchmark of single engine ops through the C ABI (for rocprofv3 --pmc runs).
-usage: python tools/bench_ops.py linear M N K [reps [res|nores [geglu]]]   |   conv B C H W Cout [reps]"""
+usage: python tools/bench_ops.py linear M N K [reps [res|nores [geglu]]]   |   conv B C H W Cout [reps]
+       python tools/bench_ops.py linear_ln M N K [reps [geglu]]      (LayerNorm folded into the projection: tango_op_linear_ln)"""
 import ctypes as C
 import os
 import sys
@@ -26,6 +27,17 @@ if kind == "linear":
     out = torch.empty(M, No, device="cuda")
     for _ in range(reps):
         assert lib.tango_op_linear(1, p(x), p(w), p(b), p(r) if use_res else None, p(out), M, N, K, 0, 0, geglu, None) == 0
+elif kind == "linear_ln":
+    M, N, K = [int(v) for v in sys.argv[2:5]]
+    reps = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+    geglu = 1 if len(sys.argv) > 6 and sys.argv[6] == "geglu" else 0
+    x = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") / K ** 0.5
+    b = torch.randn(N, device="cuda")
+    gam, bet = 1.0 + 0.1 * torch.randn(K, device="cuda"), 0.1 * torch.randn(K, device="cuda")
+    out = torch.empty(M, N // 2 if geglu else N, device="cuda")
+    for _ in range(reps):
+        assert lib.tango_op_linear_ln(1, p(x), p(w), p(b), p(gam), p(bet), None, p(out), M, N, K, geglu, 1e-5, None) == 0
 elif kind == "conv":
     B, Cc, H, W, Co = [int(v) for v in sys.argv[2:7]]
     reps = int(sys.argv[7]) if len(sys.argv) > 7 else 5
