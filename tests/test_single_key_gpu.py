@@ -99,7 +99,10 @@ def test_single_key_constant_in_the_to_out_epilogue_equals_the_separate_pass():
     _lib.load().tango_tuning_reload()
     n_sep = {k: sum(1 for lab in v if lab.startswith("xattn_single_key")) for k, v in labels.items()}
     print("separate single-key passes per step: fused %d, not fused %d" % (n_sep[1], n_sep[0]))
-    assert n_sep[0] == 16 and n_sep[1] <= 1       # the mid block (1024 rows at this batch) runs on the small tiles: its pass stays
+    # fused: the mid block (1024 rows at this batch) runs on the small tiles: its pass stays; and (round 5) the FIRST transformer of a
+    # guidance step runs its part in front of attn2 once for both halves (CFG-shared prefix), so its unconditional rows are written by
+    # the separate pass that reads the shared tensor (profile_unet reports the plan denoise() runs)
+    assert n_sep[0] == 16 and n_sep[1] <= 2
     d = ((outs[1] - outs[0]).abs().max() / outs[0].abs().max()).item()
     print("fused vs separate single-key constant: rel diff %.3e" % d)
     assert torch.isfinite(outs[1]).all() and d <= 3e-3
