@@ -89,7 +89,13 @@ template <typename T> __device__ __forceinline__ float frag_first(const u32x4& v
 // op_sel operands behind a v_xor): that form reproduces the round-1 miscompare at K = 640 16-bit (39 of 300 repeats, same
 // box, same call as 0 of 1000 for the FIX form - profiles/r2_race_hunt.txt).  Only instantiated for that one configuration
 // (TANGO_STREAM_NOFIX=1, tools/diag_stream_race.py) so the failing form stays reproducible.
-template <typename T, int KS, int TN, bool LN, bool FIX = true>
+// SPEC (round 5): 1 = the epilogue specialised at compile time for the one shape that dominates this kernel's time at config 3, the
+// level-0 GEGLU projection with the folded LayerNorm (M = 262144, N = 2560, K = 320: 3.3 ms per step, and PMC shows it VALU-bound
+// by its epilogue -- 6.1 VALU per MFMA, profiles/r5_final_pmc_gemm_pers_and_stream_geglu_summary.txt): EPI_GEGLU, no residual, no
+// transposed-V columns, staged stores, M a multiple of 32 (no row clamps / masks).  Same arithmetic in the same order as SPEC = 0 --
+// only the wave-uniform run-time tests on p.epi / p.R / p.stage_epi / m < M inside the 20 unrolled epilogue iterations and the
+// run-time divisor of the store loop are gone.  TANGO_STREAM_SPEC=0 is the A/B switch.
+template <typename T, int KS, int TN, bool LN, bool FIX = true, int SPEC = 0>
 __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) {
   constexpr int R = (TN > 5) ? 5 : 10;         // ring depth in k-steps (register budget: acc 8*TN + ring 8*R)
   constexpr int TM = 2;
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
   // next group re-reads its current one, so the main loop has NO branches: every load is unconditional.
   auto row_ptr_c = [&](int grp_, int tm) -> const unsigned char* {
     int m = grp_ * 32 + tm * 16 + l15;
-    m = m < p.M ? m : p.M - 1;
+    if (SPEC == 0) m = m < p.M ? m : p.M - 1;
     return Ab + (int64_t)m * ldab + g * 16;
   };
   u32x4 xf[R][TM];
@@ -242,27 +248,30 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
     int n0e = n0, g4e = g4;
     asm volatile("" : "+s"(n0e));
     asm volatile("" : "+v"(g4e));
+    // (SPEC == 1: every switch below is a compile-time constant)
+    const int epi = SPEC == 1 ? (int)EPI_GEGLU : p.epi;
+    const bool has_res = SPEC == 1 ? false : p.R != nullptr;
     int64_t orow[TM], vtrow[TM];
     bool rok[TM];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int m = grp * 32 + tm * 16 + l15;
-      rok[tm] = m < p.M;
+      rok[tm] = SPEC == 1 ? true : m < p.M;
       orow[tm] = rok[tm] ? m : p.M - 1; vtrow[tm] = 0;
-      if (p.epi == EPI_VT) {
+      if (epi == EPI_VT) {
         const int mm = (int)orow[tm];
         const int bb = mm / p.vt_S;
         vtrow[tm] = (int64_t)bb * (p.N - p.vt_n0) * p.vt_ld + (mm - bb * p.vt_S);
       }
     }
-    const bool panel_vt = (p.epi == EPI_VT) && n0e >= p.vt_n0;
-    const bool stage = p.stage_epi && !panel_vt && !(p.epi == EPI_VT && n0e + BN > p.vt_n0);
+    const bool panel_vt = (epi == EPI_VT) && n0e >= p.vt_n0;
+    const bool stage = SPEC == 1 ? true : (p.stage_epi && !panel_vt && !(epi == EPI_VT && n0e + BN > p.vt_n0));
     constexpr int SPITCH = BN * (int)sizeof(T) + 16;
     unsigned char* const stg = wlds + BN * ROWB + wave * (SROWS * SPITCH);
     const float* const cst = (const float*)(wlds + BN * ROWB + 8 * SROWS * SPITCH);   // [bias BN | wsum BN]
 
     T rv[TM][TN][4];
-    if (p.R) {
+    if (has_res) {
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -273,14 +282,14 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
       for (int a = 0; a < TN; ++a) {
-        if (p.epi == EPI_GEGLU && (a & 1)) continue;
+        if (epi == EPI_GEGLU && (a & 1)) continue;
         const int nt = n0e + a * 16;
         const int n = nt + g4e;
         const f32x4 cb = *(const f32x4*)(cst + a * 16 + g4e);
         const f32x4 cw = *(const f32x4*)(cst + BN + a * 16 + g4e);
         int oc = n, ocl = a * 16 + g4e;                  // output column (global / within the staged slice)
-        if (p.epi == EPI_GEGLU) { oc = (nt >> 1) + g4e; ocl = (a >> 1) * 16 + g4e; }
-        const bool to_vt = (p.epi == EPI_VT) && n >= p.vt_n0;
+        if (epi == EPI_GEGLU) { oc = (nt >> 1) + g4e; ocl = (a >> 1) * 16 + g4e; }
+        const bool to_vt = (epi == EPI_VT) && n >= p.vt_n0;
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
             v[r] = rstd[tm] * (acc[a][tm][r] - mean[tm] * cw[r]) + cb[r];
           }
         }
-        if (p.epi == EPI_GEGLU) {
+        if (epi == EPI_GEGLU) {
           const int a1 = a + 1 < TN ? a + 1 : a;
           const f32x4 gb = *(const f32x4*)(cst + a1 * 16 + g4e);
           const f32x4 gw = *(const f32x4*)(cst + BN + a1 * 16 + g4e);
@@ -311,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
           }
           glu_gate4<T>(v, gt, 0);
         }
-        if (p.R) {
+        if (has_res) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += to_f(rv[tm][a][r]);
         }
@@ -333,12 +342,12 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
       if (stage && (SROWS == 16 || tm == TM - 1)) {
         __builtin_amdgcn_wave_barrier();
         constexpr int EPV = 16 / (int)sizeof(T);
-        const int ppr = (p.epi == EPI_GEGLU ? BN / 2 : BN) / EPV;           // 16-byte pieces per output row
-        const int ocol0 = p.epi == EPI_GEGLU ? (n0e >> 1) : n0e;
+        const int ppr = (epi == EPI_GEGLU ? BN / 2 : BN) / EPV;           // 16-byte pieces per output row
+        const int ocol0 = epi == EPI_GEGLU ? (n0e >> 1) : n0e;
         for (int idx = lane; idx < SROWS * ppr; idx += 64) {
           const int row_l = idx / ppr, pcs = idx - row_l * ppr;
           const int m = grp * 32 + (SROWS == 32 ? 0 : tm * 16) + row_l;
-          if (m < p.M) {
+          if (SPEC == 1 || m < p.M) {
             const u32x4 t = *(const u32x4*)(stg + row_l * SPITCH + pcs * 16);
             *(u32x4*)((T*)p.out + (int64_t)m * p.ldo + ocol0 + pcs * EPV) = t;
           }
@@ -349,12 +358,12 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
   }
 }
 
-template <typename T, int KS, int TN, bool LN, bool FIX = true>
+template <typename T, int KS, int TN, bool LN, bool FIX = true, int SPEC = 0>
 static int stream_launch(const GemmParams& p, hipStream_t s) {
   constexpr int BN = TN * 16;
   constexpr int SROWS = 16;
   constexpr int LDS = BN * KS * 64 + 8 * SROWS * (BN * (int)sizeof(T) + 16) + 2 * BN * 4;   // weight panel + per-wave output staging + constants
-  auto kfn = lin_stream_kernel<T, KS, TN, LN, FIX>;
+  auto kfn = lin_stream_kernel<T, KS, TN, LN, FIX, SPEC>;
   TANGO_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(kfn), LDS));
   const int NP = p.N / BN;
   int rpx = 32 / NP;               // one workgroup per CU: 32 per XCD = NP panels x rpx row ranges
@@ -406,7 +415,15 @@ bool linear_stream_ok(int dtype, const GemmParams& p) {
 template <typename T>
 static int stream_t(const GemmParams& p, hipStream_t s) {
   const int rowb = p.K * (int)sizeof(T);
-  if (rowb == 640) return p.ln_fold ? stream_launch<T, 10, 10, true>(p, s) : stream_launch<T, 10, 10, false>(p, s);
+  if (rowb == 640) {
+    if constexpr (sizeof(T) == 2) {
+      // the level-0 GEGLU projection: compile-time epilogue (SPEC = 1) when every assumption it makes holds
+      constexpr int EPVH = 8;
+      if (p.ln_fold && p.epi == EPI_GEGLU && !p.R && p.M % 32 == 0 && p.ldo % EPVH == 0 && ((uintptr_t)p.out & 15) == 0 && tuning().stream_spec)
+        return stream_launch<T, 10, 10, true, true, 1>(p, s);
+    }
+    return p.ln_fold ? stream_launch<T, 10, 10, true>(p, s) : stream_launch<T, 10, 10, false>(p, s);
+  }
   if (rowb == 1280) {
     // (the FIX = false instantiation -- the epilogue form that miscompared 39 / 300 on the bf16 K = 640 LN build,
     //  profiles/r2_race_hunt.txt -- is no longer compiled into the library: tools/experiments/README.md says how to rebuild it;

@@ -33,6 +33,7 @@ struct Tuning {
   int graph_steps;          // TANGO_GRAPH_STEPS=k      denoise: k UNet steps per captured hipGraph (default 10 for UNet batches <= 16, else 1; 1 = one replay per step) (round 5)
   int unet_chains;          // TANGO_UNET_CHAINS=1|2    denoise: the UNet batch as one kernel sequence or as two independent halves in two branches of the captured graph (Engine::unet_chains_for; unset = the measured rule) (round 5)
   bool no_cfg_shared;       // TANGO_NO_CFG_SHARED=1    A/B: the CFG-shared prefix of a guidance step (conv_in ... first self-attention once for both halves) off (round 5)
+  bool stream_spec;         // TANGO_STREAM_SPEC=0|1     lin_stream_kernel: compile-time GEGLU + folded-LayerNorm epilogue for the level-0 projection (default on) (round 5)
   int attn_qb2_min_wgs;     // TANGO_ATTN_QB2_MIN_WGS=n attention with Sq <= 512: 32 query rows per wave once that still leaves n workgroups (default 512: level-2 self-attention at B=32 0.319 -> 0.247 ms, profiles/r4_c14_attn_qb2_ab_b32.txt); 0 = never (round 4)
   int gn_small_mb;          // TANGO_GN_SMALL_MB=n      GroupNorm: the one-launch (sample, group)-per-workgroup kernel up to n MiB of input (default 8)
   int wide_pers;            // TANGO_WIDE_PERS=n        256 x 320 GEMM: the persistent form (next tile's first chunk prefetched behind the epilogue) from n tiles per CU on (default 2: linears of a B = 32 step 20.0 -> 19.7 ms, bit-identical results, profiles/r4_c16_wide_pers_ab_b32.txt); 0 = never (round 4)
@@ -67,6 +68,7 @@ inline Tuning read_tuning() {
   x.graph_steps = num("TANGO_GRAPH_STEPS", 0);
   x.unet_chains = num("TANGO_UNET_CHAINS", 0);
   x.no_cfg_shared = on("TANGO_NO_CFG_SHARED");
+  x.stream_spec = num("TANGO_STREAM_SPEC", 1) != 0;
   x.attn_qb2_min_wgs = num("TANGO_ATTN_QB2_MIN_WGS", 512);
   x.gn_small_mb = num("TANGO_GN_SMALL_MB", 8);
   x.wide_pers = num("TANGO_WIDE_PERS", 2);
