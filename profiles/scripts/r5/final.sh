@@ -2,7 +2,7 @@
 # Round-5 end-of-round evidence on the final tree: full GPU suite, the driver's default bench line, rocprofv3 kernel stats of the bench
 # command, HBM-side PMC passes (N = 2 and N = 6 steps), PMC view of the GEMM kernels incl. the level-0 streaming GEGLU projection.
 set -x
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/final6; mkdir -p $OUT
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/final7; mkdir -p $OUT
 export TANGO_TEST_THREADS=16
 cd $R
 ( timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | grep -v Warning | tail -15 ) > $OUT/tests_gpu.log 2>&1
@@ -35,6 +35,6 @@ cd $R
 timeout 300 python tools/profile_unet_ops.py --batch 32 --out $OUT/unet_ops_b32.txt > /dev/null 2>&1
 timeout 300 python tools/profile_unet_ops.py --batch 8 --out $OUT/unet_ops_b8.txt > /dev/null 2>&1
 timeout 300 python tools/profile_unet_ops.py --batch 1 --out $OUT/unet_ops_b1.txt > /dev/null 2>&1
-PMC_OUT=final6/pmc bash tools/pmc_op.sh run gemm_wide_pers_res_l1 gemm_wide_pers linear 65536 640 640 3 res > /dev/null 2>&1
-PMC_OUT=final6/pmc2 bash tools/pmc_op.sh run stream_ln_geglu_l0 lin_stream linear_ln 262144 2560 320 3 geglu > /dev/null 2>&1
+PMC_OUT=final7/pmc bash tools/pmc_op.sh run gemm_wide_pers_res_l1 gemm_wide_pers linear 65536 640 640 3 res > /dev/null 2>&1
+PMC_OUT=final7/pmc2 bash tools/pmc_op.sh run stream_ln_geglu_l0 lin_stream linear_ln 262144 2560 320 3 geglu > /dev/null 2>&1
 cat $OUT/pmc/summary.txt $OUT/pmc2/summary.txt | grep -E "##|derived|FETCH|WRITE"

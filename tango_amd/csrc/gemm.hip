@@ -335,6 +335,7 @@ static int launch_t(const GemmParams& p, hipStream_t s) {
   const int cb = p.Cin * (int)sizeof(T);
   if (p.M <= 0 || p.N <= 0) return 0;
   if (p.K % p.Cin != 0) TANGO_FAIL("gemm: K must be taps*Cin");
+  if (p.a_act != ACT_NONE && p.a_act != ACT_LRELU && p.a_act != ACT_SILU) TANGO_FAIL("gemm: the operand prologue implements leaky-ReLU and SiLU only");
   if ((p.lda * (int64_t)sizeof(T)) % 16 != 0 || (p.Kp * (int64_t)sizeof(T)) % 16 != 0) TANGO_FAIL("gemm: lda/Kp must be 16-byte multiples");
   if (cb % 128 == 0) return launch_mode<T, 128>(p, s);
   if (cb % 64 == 0) return launch_mode<T, 64>(p, s);
@@ -412,7 +413,10 @@ bool gemm_rowvec_ok(int dtype, const GemmParams& p) {
 
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
   if (p.rowvec && !gemm_rowvec_ok(dtype, p)) TANGO_FAIL("gemm: rowvec is only implemented by the 256 x 320 / 256 x 160 GEMM epilogues");
-  switch (gemm_route(dtype, p)) {
+  const int route = gemm_route(dtype, p);
+  if (p.glu_tanh && dtype != DT_F32 && route != ROUTE_WIDE && route != ROUTE_DUO)
+    TANGO_FAIL("gemm: the tanh-GELU gate (T5 gated-gelu) is implemented by the fp32 kernels and the 256 x 320 / 256 x 160 GEMMs only");
+  switch (route) {
     case ROUTE_WIDE: return launch_gemm_wide(dtype, p, s);
     case ROUTE_DUO: return launch_gemm_duo(dtype, p, s);
     case ROUTE_STREAM: return launch_linear_stream(dtype, p, s);

@@ -28,12 +28,22 @@ template <> struct Mma<bf16> {
   }
 };
 
+// Prologue activation on one 16-byte operand piece (the vocoder's `conv(leaky_relu(x))`, hifigan/models.py:96-103).  The wave-uniform
+// dispatch on `act` sits OUTSIDE the element loop (round 5): written per element, hipcc inlined the whole apply_act switch -- tanh, erf
+// and exp code included -- eight times per piece, inside the k-loop of the tile kernels (12 500 instructions in front of the first MFMA
+// of gemm_kernel<f16, 128, 128, 128, 2, 2, CONV1D>, a scalar compare-and-branch chain per ELEMENT), which made the vocoder's `a_act`
+// convolutions VALU / branch-bound at ~200 TFLOP/s.  Same arithmetic per element, so results are bit-identical.
 template <typename T> __device__ __forceinline__ u32x4 act_vec(u32x4 v, int act, float slope) {
   constexpr int EPV = 16 / sizeof(T);
   T e[EPV];
   __builtin_memcpy(e, &v, 16);
+  if (act == ACT_LRELU) {
 #pragma unroll
-  for (int i = 0; i < EPV; ++i) e[i] = from_f<T>(apply_act(to_f(e[i]), act, slope));
+    for (int i = 0; i < EPV; ++i) { const float x = to_f(e[i]); e[i] = from_f<T>(x > 0.f ? x : x * slope); }
+  } else {      // ACT_SILU: the only other prologue the launcher admits (gemm.hip launch_t)
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) e[i] = from_f<T>(silu_f(to_f(e[i])));
+  }
   __builtin_memcpy(&v, e, 16);
   return v;
 }
@@ -44,11 +54,16 @@ enum : int { MODE_LINEAR = 0, MODE_CONV2D = 1, MODE_CONV1D = 2 };
 // (A paired-tile variant with 16-byte residual loads/stores was measured in round 1: correct, not faster -- the
 // cross-lane exchange costs what the wider accesses save.  Note for future work: cross-lane intrinsics are
 // `convergent`; LLVM refuses to fully unroll loops containing them and the accumulator array then lands in scratch.)
-template <typename T, int TM, int TN, int MODE>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[TN][TM], const int m_base, const int n_base,
-                                              const int lane, const int zb, const int split) {
+// EPIK / ACTK / F32K >= 0: that epilogue kind / activation / output kind fixed at compile time; -1: read from GemmParams at run time
+// (round 5: see gemm_epilogue below -- the dispatch happens ONCE, outside the TM x TN unrolled loop)
+template <typename T, int TM, int TN, int MODE, int EPIK, int ACTK, int F32K>
+__device__ __forceinline__ void gemm_epilogue_body(const GemmParams& p, f32x4 (&acc)[TN][TM], const int m_base, const int n_base,
+                                                   const int lane, const int zb, const int split) {
   // ---------------- epilogue ----------------
   const int g4 = (lane >> 4) * 4;
+  const int epi = EPIK >= 0 ? EPIK : p.epi;
+  const int e_act = ACTK >= 0 ? ACTK : p.e_act;
+  const bool out_f32 = F32K >= 0 ? (F32K != 0) : (p.out_f32 != 0);
   if (p.splitk > 1) {   // raw fp32 partial tile -> workspace; the reduce kernel finishes the job
     float* wsb = p.ws + (int64_t)split * p.M * p.N;
 #pragma unroll
@@ -72,7 +87,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
   if (p.bias2) bias2 = p.bias2 + (int64_t)(p.step_ptr ? *p.step_ptr : 0) * p.bias2_stride;
   unsigned char* Ob = (unsigned char*)p.out;
   const unsigned char* Rb = (const unsigned char*)p.R;
-  const int osz = p.epi == EPI_I16 ? 2 : (p.out_f32 ? 4 : (int)sizeof(T));
+  const int osz = epi == EPI_I16 ? 2 : (out_f32 ? 4 : (int)sizeof(T));
   Ob += (int64_t)zb * p.sO * osz;
   if (Rb) Rb += (int64_t)zb * p.sR * (int64_t)sizeof(T);
 
@@ -82,7 +97,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     const int m = m_base + b * 16 + (lane & 15);
     orow[b] = -1; vtrow[b] = 0;
     if (m < p.M) {
-      if (p.epi == EPI_VT) {
+      if (epi == EPI_VT) {
         const int bb = m / p.vt_S;
         vtrow[b] = (int64_t)bb * (p.N - p.vt_n0) * p.vt_ld + (m - bb * p.vt_S);
       }
@@ -97,7 +112,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 
 #pragma unroll
   for (int a = 0; a < TN; ++a) {
-    if (p.epi == EPI_GEGLU && (a & 1)) continue;
+    if (epi == EPI_GEGLU && (a & 1)) continue;
     const int nt = n_base + a * 16;   // tile base column (packed order)
     const int n = nt + g4;
     if (n >= p.N) continue;
@@ -109,14 +124,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         if (n + r < p.N) {
           if (bias) cb[r] = bias[n + r];
           if (bias2) cb[r] += bias2[n + r];
-          if (p.epi == EPI_GEGLU && bias) cg[r] = bias[n + 16 + r];
+          if (epi == EPI_GEGLU && bias) cg[r] = bias[n + 16 + r];
         }
       }
     }
     int oc = n, ncols = p.N;
-    if (p.epi == EPI_GEGLU) { oc = (nt >> 1) + g4; ncols = p.N >> 1; }
-    const bool to_vt = (p.epi == EPI_VT) && n >= p.vt_n0;
-    if (p.epi == EPI_VT) ncols = p.vt_n0;
+    if (epi == EPI_GEGLU) { oc = (nt >> 1) + g4; ncols = p.N >> 1; }
+    const bool to_vt = (epi == EPI_VT) && n >= p.vt_n0;
+    if (epi == EPI_VT) ncols = p.vt_n0;
     const bool full = (oc + 3 < ncols);
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
@@ -125,15 +140,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       const float rb = (bias && p.bias_rows) ? bias[orow[b]] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha + cb[r] + rb;
-      if (p.epi == EPI_GEGLU) {
+      if (epi == EPI_GEGLU) {
         // packed rows: [16 value | 16 gate] blocks -> out col = nt/2 + g4 + r
         float gt[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) gt[r] = acc[a + 1 < TN ? a + 1 : a][b][r] * p.alpha + cg[r];
-        glu_gate4<T>(v, gt, p.glu_tanh);
-      } else if (p.e_act != ACT_NONE) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.e_act, p.e_slope);
+        if constexpr (sizeof(T) == 2) glu_gate4<T>(v, gt, 0);      // 16-bit: exact-erf polynomial gate only (launch_gemm refuses glu_tanh here): the tanh
+        else glu_gate4<T>(v, gt, p.glu_tanh);                       // form's ocml code at every unrolled call site was most of these epilogues' 30 000 instructions
+      } else if (e_act != ACT_NONE) {
+        apply_act4(v, e_act, p.e_slope);
       }
       if (Rb) {
         const T* rp = (const T*)Rb + orow[b] * p.ldr + oc;
@@ -155,11 +170,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         T* vp = (T*)p.vt + vtrow[b] + (int64_t)(n - p.vt_n0) * p.vt_ld;
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (n + r < p.N) vp[(int64_t)r * p.vt_ld] = from_f<T>(v[r]);
-      } else if (p.epi == EPI_I16) {
+      } else if (epi == EPI_I16) {
         int16_t* op = (int16_t*)Ob + orow[b] * p.ldo + oc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (oc + r < ncols) op[r] = (int16_t)(int)v[r];   // C truncation, int16 wrap (hifigan/utilities.py:81)
-      } else if (p.out_f32) {
+      } else if (out_f32) {
         float* op = (float*)Ob + orow[b] * p.ldo + oc;
         if (full && ((p.ldo | oc) & 3) == 0) {
           *(f32x4*)op = f32x4{v[0], v[1], v[2], v[3]};
@@ -183,6 +198,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
   }
 }
 
+
+// Shared epilogue of the tile / LDS-DMA gather kernels.  Round 5: the TM x TN unrolled loop used to test p.epi / p.e_act / p.out_f32
+// in every iteration, with the code of EVERY epilogue kind and every activation (tanh, erf, exp) inlined at every call site: 30 000
+// instructions per kernel, of which a launch executes a sparse few -- a chain of jumps over kilobytes of dead code per iteration
+// (the kernels of the B = 1 path, the vocoder and the VAE).  Now the kind is dispatched ONCE and the common ones run straight-line,
+// specialised bodies; anything else takes the fully run-time body (identical arithmetic in every body).
+template <typename T, int TM, int TN, int MODE>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[TN][TM], const int m_base, const int n_base,
+                                              const int lane, const int zb, const int split) {
+  if (p.epi == EPI_NONE && !p.out_f32) {
+    if (p.e_act == ACT_NONE) return gemm_epilogue_body<T, TM, TN, MODE, EPI_NONE, ACT_NONE, 0>(p, acc, m_base, n_base, lane, zb, split);
+    if (p.e_act == ACT_LRELU) return gemm_epilogue_body<T, TM, TN, MODE, EPI_NONE, ACT_LRELU, 0>(p, acc, m_base, n_base, lane, zb, split);
+  }
+  if (p.epi == EPI_GEGLU && !p.out_f32) return gemm_epilogue_body<T, TM, TN, MODE, EPI_GEGLU, ACT_NONE, 0>(p, acc, m_base, n_base, lane, zb, split);
+  if (p.epi == EPI_VT && !p.out_f32 && p.e_act == ACT_NONE) return gemm_epilogue_body<T, TM, TN, MODE, EPI_VT, ACT_NONE, 0>(p, acc, m_base, n_base, lane, zb, split);
+  gemm_epilogue_body<T, TM, TN, MODE, -1, -1, -1>(p, acc, m_base, n_base, lane, zb, split);
+}
+
 // LDS-staged epilogue for the 8-wave kernels (plain outputs: EPI_NONE, storage dtype T).
 // The direct epilogue above stores 8 bytes per lane = 32-byte runs per output row; measured on the level-0 conv
 // (ablation in profiles/r1_v16_conv_halo_ablation.txt) those partial-line writes cost 175 us of a 660 us kernel.
@@ -191,16 +224,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // with 16-byte pieces: residual read, add, scale, convert, 16-byte store -> TN*16*sizeof(T)-byte contiguous runs.
 // Caller guarantees: all waves are past their last LDS read (barrier), p.epi is EPI_NONE or EPI_GEGLU, !p.out_f32, n_base + TN*16 <= N,
 // ldo / ldr multiples of 16/sizeof(T), 16-byte aligned out / R.
-template <typename T, int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4 (&acc)[TN][TM], const int m_base, const int n_base,
-                                                     const int lane, unsigned char* stage) {
+// KIND (round 5, as gemm_epilogue above): 0 = plain (EPI_NONE, no activation), 1 = GEGLU, -1 = read p.epi / p.e_act at run time
+template <typename T, int TM, int TN, int KIND>
+__device__ __forceinline__ void gemm_epilogue_staged_body(const GemmParams& p, f32x4 (&acc)[TN][TM], const int m_base, const int n_base,
+                                                          const int lane, unsigned char* stage) {
   constexpr int EPV = 16 / (int)sizeof(T);
   constexpr int WN = TN * 16;
   constexpr int PITCH = WN * 4 + 16;       // bytes per staged row (+16: spreads rows over the banks)
   constexpr int PPR = WN / EPV;            // 16-byte output pieces per row
   static_assert((32 * PPR) % 128 == 0 || (TN & 1), "staged epilogue: 32 rows must split into whole wave passes (also at half width for GEGLU)");
   const int g4 = (lane >> 4) * 4;
-  const bool geglu = p.epi == EPI_GEGLU;
+  const bool geglu = KIND >= 0 ? (KIND == 1) : (p.epi == EPI_GEGLU);
+  const int e_act = KIND >= 0 ? (int)ACT_NONE : p.e_act;
   const float* bias = p.bias;
   const float* bias2 = p.bias2 ? p.bias2 + (int64_t)(p.step_ptr ? *p.step_ptr : 0) * p.bias2_stride : nullptr;
   float cb[TN][4];
@@ -236,10 +271,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4 
           float gt[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) gt[r] = acc[ag][b][r] * p.alpha + cb[ag][r];
-          glu_gate4<T>(v, gt, p.glu_tanh);
-        } else if (p.e_act != ACT_NONE) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.e_act, p.e_slope);
+          if constexpr (sizeof(T) == 2) glu_gate4<T>(v, gt, 0);      // 16-bit: exact-erf polynomial gate only (launch_gemm refuses glu_tanh here): the tanh
+        else glu_gate4<T>(v, gt, p.glu_tanh);                       // form's ocml code at every unrolled call site was most of these epilogues' 30 000 instructions
+        } else if (e_act != ACT_NONE) {
+          apply_act4(v, e_act, p.e_slope);
         }
         *(f32x4*)(stage + row_l * PITCH + ((geglu ? (a >> 1) : a) * 16 + g4) * 4) = v;
       }
@@ -276,6 +311,14 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4 
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4 (&acc)[TN][TM], const int m_base, const int n_base,
+                                                     const int lane, unsigned char* stage) {
+  if (p.epi == EPI_NONE && p.e_act == ACT_NONE) return gemm_epilogue_staged_body<T, TM, TN, 0>(p, acc, m_base, n_base, lane, stage);
+  if (p.epi == EPI_GEGLU) return gemm_epilogue_staged_body<T, TM, TN, 1>(p, acc, m_base, n_base, lane, stage);
+  gemm_epilogue_staged_body<T, TM, TN, -1>(p, acc, m_base, n_base, lane, stage);
 }
 
 // host-side predicate for the staged epilogue
