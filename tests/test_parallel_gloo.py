@@ -138,3 +138,20 @@ def test_generate_for_batch_dp_two_ranks(samples):
     else:
         assert all(len(g) == samples for g in out)
         assert all(np.array_equal(a, b) for g, h in zip(out, single) for a, b in zip(g, h))
+
+
+def test_single_process_keeps_a_host_mask_on_the_host():
+    """without a process group the generator must hand the tokenizer's HOST mask through untouched -- the engine then picks
+    its plan from it instead of reading a device copy back (Engine.denoise `prompt_mask_host`); with a group the mask is broadcast."""
+    seen = {}
+
+    def compute(pe, pm, offset, seed=0):
+        seen["mask_device"] = pm.device.type
+        seen["mask_dtype"] = pm.dtype
+        return _fake_compute(pe, pm, offset, seed)
+
+    pe, pm = _global_inputs(3, 4, 6)
+    out = DataParallelGenerator(compute, torch.device("cpu")).generate(pe, pm, 3.0, N_SAMPLES, seed=1)
+    assert out.shape == (3, N_SAMPLES) and seen["mask_device"] == "cpu" and seen["mask_dtype"] == torch.bool
+    dp = DataParallelGenerator(compute, torch.device("cpu"))
+    assert dp.collective is False and dp.world == 1 and dp.rank == 0
