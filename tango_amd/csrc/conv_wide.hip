@@ -17,6 +17,7 @@
 // Reference op replaced: the ResnetBlock2D 3x3 convolutions and the up-/down-sampler convolutions of the UNet
 // (diffusers/src/diffusers/models/resnet.py:445-552), i.e. ATen convolution.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "tuning.h"
@@ -27,7 +28,10 @@ namespace tango {
 
 static constexpr int CW_HALO_MAX = 544;    // halo pixels per tile: 2 x 34 KiB halo + 80 KiB weight ring + 12 KiB source offsets = the whole 160-KiB LDS
                                            // (544 = four 32 x 2 images with their borders: the UNet's level 3)
-static constexpr int CW_NA = 5;            // halo DMA pieces (16 rows) per wave per channel chunk: 8 waves x 5 x 16 rows >= 544
+static constexpr int CW_NA_WIDE = 5;       // halo DMA pieces (16 rows) per wave per channel chunk: 8 waves x 5 x 16 rows >= 544
+static constexpr int CW_NA = CW_NA_WIDE;
+static constexpr int CW_HALO_MAX_TALL = 800;   // 512-pixel tile: two 64 x 4 images with their borders (level 2) = 792 halo pixels; 2 x 50 KiB halo + 40 KiB weight ring + 16 KiB offsets
+static constexpr int CW_NA_TALL = 7;       // 8 waves x 7 x 16 rows >= 800
 
 // SCH: where the LDS-DMAs of an item (one halo piece of the next chunk during taps 0..4, the weight rows of item i+3) are issued
 // (round 4, as in gemm_wide.hip):
@@ -39,14 +43,20 @@ static constexpr int CW_NA = 5;            // halo DMA pieces (16 rows) per wave
 // very start, from registers: = 0; all of them there: 9 % slower than 0), paired DMAs after MFMAs 8 and 24 (= 1), a "lean"
 // multiply part with the scalar address preparation pinned in the read part (5 % slower than 1), 32x32x16 MFMAs (probe: -5 %).
 // PRIO: see gemm_wide.hip.
-template <typename T, bool RES, bool SK, int SCH>
+//
+// TALL (round 6): the same eight 64 x 160 wave tiles stacked as 512 pixels x 160 channels.  The halo makes the activation operand
+// nearly free (staged once per chunk for nine items), so what an item streams through the DMA engine is its weight rows: 160
+// instead of 320 per item for the same 320 MFMAs per wave pair, and a halo of 512 pixels has fewer border pixels per output pixel --
+// 14.3 instead of 22.3 KiB of LDS-DMA per item at level 0.  Same MFMA order per accumulator, same epilogue: bit-identical results.
+template <typename T, bool RES, bool SK, int SCH, bool TALL>
 __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, const unsigned char* zero_page, const int SR, const int nseg,
                                                            const int abytes, const int prio) {
-  constexpr int BM = 256, BN = 320, CB = 64, NST = 4;
+  constexpr int BM = TALL ? 512 : 256, BN = TALL ? 160 : 320, CB = 64, NST = 4;
+  constexpr int CW_NA = TALL ? CW_NA_TALL : CW_NA_WIDE;
   constexpr int BK = CB / (int)sizeof(T);       // 32 channels per chunk
   constexpr int WST = BN * CB;                  // bytes per weight stage
   constexpr int WRG = BN / 16;                  // 16-row DMA groups per weight item: 20
-  constexpr int WRGW = (WRG + 7) / 8;           // per wave: 3 (waves 0-3) or 2
+  constexpr int WRGW = (WRG + 7) / 8;           // per wave: 3 (waves 0-3) or 2; TALL: 2 (waves 0-1) or 1
   constexpr int TM = 4, TN = 10;
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // [halo 0 | halo 1 | W stage 0..3]
   unsigned char* const As = dsm;
@@ -63,10 +73,10 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
   const unsigned char* Wb = (const unsigned char*)p.W;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 3, wn = wave >> 2;
+  const int wm = TALL ? wave : wave & 3, wn = TALL ? 0 : wave >> 2;
   const int lrow = lane >> 2, slot = lane & 3;
 
-  // tile geometry: 256 consecutive pixels = SR image rows of one image (nseg == 1) or nseg whole images
+  // tile geometry: BM consecutive pixels = SR image rows of one image (nseg == 1) or nseg whole images
   const int H = p.H, Wd = p.Wd, hw = H * Wd;
   const int HW2 = Wd + 2, SEG = (SR + 2) * HW2;
   const int HALO = nseg * SEG, HALO_RG = (HALO + 15) >> 4;
@@ -154,7 +164,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
 #pragma unroll
   for (int b = 0; b < TM; ++b) {
     const int pm = wm * 64 + b * 16 + (lane & 15);
-    const int seg = pm / hw, r = pm - seg * hw;      // nseg == 1: hw >= 256 > pm -> seg = 0
+    const int seg = pm / hw, r = pm - seg * hw;      // nseg == 1: hw >= BM > pm -> seg = 0
     const int ly = r / Wd, x = r - ly * Wd;
     const int hb_ = seg * SEG + ly * HW2 + x;
     if (b == 0) h0 = hb_;
@@ -261,23 +271,282 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const GemmParams p, c
   wide_epilogue<T, false, RES, false>(p, acc, mean, rstd, m0 + wm * 64, n0 + wn * (TN * 16), lane, slice);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// In-wave software pipeline (round 6; gemm_wide.hip: gemm_wide_pipe_kernel has the schedule and its proof).  Same LDS image (two
+// halo buffers, four weight stages), same DMA source layout.  During item i a wave multiplies the fragments it holds and refills them
+// in place for item i+1 (wf[a] right behind column group a, xf[b] behind its last use in group 9; fragment reads from inline asm,
+// one lgkmcnt(0) per item); the weights of item i+4 go into the stage item i was read from (by everybody, during item i-1), the halo
+// piece of the next channel chunk rides in items (cc, 0..4) as before.  Two half-items of 20 MFMAs, a raw barrier behind each, the
+// 4-wave halves one barrier apart.  vmcnt: per wave the queue is ... hp(i-2) W(i+2) hp(i-1) W(i+3) at the end of H0(i), where W(i+2)
+// (and with it every older halo piece) must have landed one barrier before anybody reads it: at most hp(i-1) + |W(i+3)| stay in flight.
+// Same MFMA order per accumulator as conv3x3_wide_kernel: bit-identical results.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int OFF> __device__ __forceinline__ void cwp_lds_read(u32x4& v, const unsigned base) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(OFF));
+}
+__device__ __forceinline__ void cwp_lds_wait_all(u32x4 (&wf)[10], u32x4 (&xf)[4], unsigned& hoff) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(wf[4]), "+v"(wf[5]), "+v"(wf[6]), "+v"(wf[7]), "+v"(wf[8]), "+v"(wf[9]),
+                 "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]), "+v"(hoff));
+}
+// the halo piece's source offset for the NEXT item, read with the fragments (a compiler-visible LDS load here makes hipcc wait
+// lgkmcnt(0) in front of every DMA of the item: the load's destination register is reused for their offsets)
+__device__ __forceinline__ void cwp_lds_read_b32(unsigned& v, const unsigned addr) { asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr)); }
+template <int I, int N, typename F> __device__ __forceinline__ void cwp_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); cwp_for<I + 1, N>(f); }
+}
+
+template <typename T, bool RES, bool SK>
+__global__ __launch_bounds__(512) void conv3x3_wide_pipe_kernel(const GemmParams p, const unsigned char* zero_page, const int SR, const int nseg,
+                                                                const int abytes, const int prio) {
+  constexpr int BM = 256, BN = 320, CB = 64, NST = 4;
+  constexpr int BK = CB / (int)sizeof(T);
+  constexpr int WST = BN * CB;
+  constexpr int WRG = BN / 16;
+  constexpr int WRGW = (WRG + 7) / 8;
+  constexpr int TM = 4, TN = 10;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // [halo 0 | halo 1 | W stage 0..3 | source offsets]
+  unsigned char* const As = dsm;
+  unsigned char* const Ws = dsm + 2 * abytes;
+
+  const int NT = p.N / BN;
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (bid / NT) * BM, n0 = (bid % NT) * BN;
+  const unsigned char* Ab = (const unsigned char*)p.A;
+  const unsigned char* Wb = (const unsigned char*)p.W;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int lrow = lane >> 2, slot = lane & 3;
+
+  const int H = p.H, Wd = p.Wd, hw = H * Wd;
+  const int HW2 = Wd + 2, SEG = (SR + 2) * HW2;
+  const int HALO = nseg * SEG, HALO_RG = (HALO + 15) >> 4;
+  const int b0 = m0 / hw;
+  const int y0 = nseg == 1 ? (m0 - b0 * hw) / Wd : 0;
+
+  unsigned* const aoff_lds = (unsigned*)(Ws + NST * WST) + tid;   // [CW_NA halo pieces | weight group 0] x 512 threads (conv3x3_wide_kernel)
+#pragma unroll
+  for (int t = 0; t < CW_NA; ++t) {
+    unsigned off = ~0u;
+    const int h = ((t * 8 + wave) << 4) + lrow;
+    if (h < HALO) {
+      const int seg = h / SEG, rem = h - seg * SEG;
+      const int hy = rem / HW2, hx = rem - hy * HW2;
+      const int y = y0 + hy - 1, x = hx - 1;
+      const int pc = slot ^ ((h >> 1) & 2);
+      if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)Wd)
+        off = (unsigned)(((((int64_t)(b0 + seg) * p.Hin + (y >> p.ups)) * p.Win + (x >> p.ups)) * p.lda) * (int64_t)sizeof(T) + pc * 16);
+    }
+    aoff_lds[t * 512] = off;
+  }
+  const int wrow_d = wave * 16 + lrow;
+  const unsigned w_off0_init = (unsigned)(((int64_t)wrow_d * p.Kp) * (int64_t)sizeof(T) + ((slot ^ ((wrow_d >> 1) & 2)) * 16));
+  const unsigned w_step = (unsigned)(128 * p.Kp * (int64_t)sizeof(T));
+  const unsigned char* const Wt = Wb + (int64_t)n0 * p.Kp * (int64_t)sizeof(T);
+  const int my_w = wave < WRG - 8 * (WRGW - 1) ? WRGW : WRGW - 1;      // wave-uniform: 3 (waves 0-3) or 2
+
+  auto issue_a_off = [&](const int t, const int cc, const int buf, const unsigned off) {
+    const unsigned char* src = off != ~0u ? Ab + (int64_t)cc * CB + off : zero_page;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * abytes + (t * 8 + wave) * 1024), 16, 0, 0);
+  };
+  auto issue_w_one = [&](const int i, int koff, const int st, const unsigned w_off0) {
+    const int rg = wave + 8 * i;
+    if (rg < WRG) {
+      asm volatile("" : "+s"(koff));
+      const unsigned char* base = Wt + koff;
+      unsigned o = w_off0 + i * w_step;
+      asm volatile("" : "+v"(o));
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + o), (lptr_t)(Ws + st * WST + rg * 1024), 16, 0, 0);
+    }
+  };
+  auto wait_n = [&](const int n) {
+    switch (n) {
+      case 0: wait_vmcnt_lit<0>(); break;
+      case 1: wait_vmcnt_lit<1>(); break;
+      case 2: wait_vmcnt_lit<2>(); break;
+      case 3: wait_vmcnt_lit<3>(); break;
+      case 4: wait_vmcnt_lit<4>(); break;
+      case 5: wait_vmcnt_lit<5>(); break;
+      default: wait_vmcnt_lit<6>(); break;
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int h0 = 0, hd[TM];
+#pragma unroll
+  for (int b = 0; b < TM; ++b) {
+    const int pm = wm * 64 + b * 16 + (lane & 15);
+    const int seg = pm / hw, r = pm - seg * hw;
+    const int ly = r / Wd, x = r - ly * Wd;
+    const int hb_ = seg * SEG + ly * HW2 + x;
+    if (b == 0) h0 = hb_;
+    hd[b] = __builtin_amdgcn_readfirstlane(hb_ - h0);
+  }
+  const int kg = lane >> 4;
+  const int wrow0 = wn * (TN * 16) + (lane & 15);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
+  const unsigned wbase = lds0 + (unsigned)(2 * abytes) + (unsigned)(wrow0 * CB + ((kg ^ ((wrow0 >> 1) & 2)) << 4));
+
+  int cc0 = 0, cc1 = p.Cin / BK;
+  if (SK) {
+    const int per = (cc1 + (int)gridDim.y - 1) / (int)gridDim.y;
+    cc0 = (int)blockIdx.y * per;
+    cc1 = cc1 < cc0 + per ? cc1 : cc0 + per;
+  }
+  const int NI = (cc1 - cc0) * 9;                   // >= 9
+
+  const int half = wave >> 2;
+  // LDS address of this lane's activation fragment b of (halo buffer `buf`, tap offset `toff`)
+  auto xaddr = [&](const int b, const int buf, const int toff) -> unsigned {
+    int hs = hd[b] + toff;
+    asm volatile("" : "+s"(hs));
+    const int h = h0 + hs;
+    return lds0 + (unsigned)(buf * abytes + h * CB + ((kg ^ ((h >> 1) & 2)) << 4));
+  };
+  // prologue: halo of chunk cc0, weight items 0..3; halo and items 0, 1 must have landed before the first reads
+  {
+#pragma unroll
+    for (int t = 0; t < CW_NA; ++t)
+      if (t * 8 + wave < HALO_RG) issue_a_off(t, cc0, cc0 & 1, aoff_lds[t * 512]);
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      const int koff = (j * p.Cin + cc0 * BK) * (int)sizeof(T);
+#pragma unroll
+      for (int i = 0; i < WRGW; ++i) issue_w_one(i, koff, j, w_off0_init);
+    }
+  }
+  wait_n(2 * my_w);
+  pp_barrier();
+  u32x4 wf[TN], xf[TM];
+  cwp_for<0, TN>([&](auto a_tag) { constexpr int a = decltype(a_tag)::value; cwp_lds_read<a * 16 * CB>(wf[a], wbase); });
+  cwp_for<0, TM>([&](auto b_tag) { constexpr int b = decltype(b_tag)::value; cwp_lds_read<0>(xf[b], xaddr(b, cc0 & 1, 0)); });
+  const unsigned aoff_addr = (unsigned)(uintptr_t)(lptr_t)aoff_lds;
+  unsigned hoff0;
+  cwp_lds_read_b32(hoff0, aoff_addr);               // item 0 issues halo piece 0 of chunk cc0 + 1
+  cwp_lds_wait_all(wf, xf, hoff0);
+  __builtin_amdgcn_sched_barrier(0);
+  if (half) pp_barrier();                           // the stagger
+  if (prio == 2 && half) __builtin_amdgcn_s_setprio(1);
+  unsigned w_off0 = w_off0_init;
+  asm volatile("" : "+v"(w_off0));
+  // one item; MORE1: item + 1 exists (refill the fragments) -- compile-time, the last item is peeled.  prev_h: did the previous item
+  // issue a halo piece; returns the same for this item.  (tap, cc, prev_h by value: captured by reference and modified here they
+  // went to scratch, with a vmcnt(0) reload at the head of every item)
+  auto do_item = [&](auto more1_tag, const int item, const int tap, const int cc, const int prev_h, unsigned& hoff) __attribute__((always_inline)) -> int {
+    constexpr bool MORE1 = decltype(more1_tag)::value;
+    const bool more_c = cc + 1 < cc1;
+    // item + 1: tap / halo buffer
+    const int tap1 = tap == 8 ? 0 : tap + 1;
+    const int buf1 = tap == 8 ? ((cc + 1) & 1) : (cc & 1);
+    const int toff1 = (tap1 / 3) * HW2 + (tap1 % 3);
+    unsigned wsrc = wbase + (unsigned)((item + 1) & (NST - 1)) * WST;
+    asm volatile("" : "+v"(wsrc));
+    // what this item issues (in H1): halo piece `tap` of chunk cc+1, weight rows of item + 4 into the stage of this item
+    const bool iss_h = more_c && tap < CW_NA && tap * 8 + wave < HALO_RG;
+    const bool iss_w = item + NST < NI;
+    const int st4 = item & (NST - 1);
+    int koff4;
+    {
+      int t4 = tap + NST, c4 = cc;
+      if (t4 >= 9) { t4 -= 9; c4 = cc + 1; }
+      koff4 = (t4 * p.Cin + c4 * BK) * (int)sizeof(T);
+    }
+    // ---- H0: column groups 0-4 ----
+    cwp_for<0, 5>([&](auto a_tag) {
+      constexpr int a = decltype(a_tag)::value;
+#pragma unroll
+      for (int b = 0; b < TM; ++b) Mma<T>::run(acc[a][b], wf[a], xf[b]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (MORE1) cwp_lds_read<a * 16 * CB>(wf[a], wsrc);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (item + 2 < NI) wait_n(prev_h + (item + 3 < NI ? my_w : 0));
+    pp_barrier();
+    // ---- H1: column groups 5-9 and this item's DMAs ----
+    unsigned xa[TM];
+#pragma unroll
+    for (int b = 0; b < TM; ++b) xa[b] = MORE1 ? xaddr(b, buf1, toff1) : 0u;
+    cwp_for<5, 9>([&](auto a_tag) {
+      constexpr int a = decltype(a_tag)::value;
+#pragma unroll
+      for (int b = 0; b < TM; ++b) Mma<T>::run(acc[a][b], wf[a], xf[b]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (MORE1) cwp_lds_read<a * 16 * CB>(wf[a], wsrc);
+      if (a == 5) { if (iss_h) issue_a_off(tap, cc + 1, (cc + 1) & 1, hoff); }
+      else if (iss_w) issue_w_one(a - 6, koff4, st4, w_off0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    cwp_for<0, TM>([&](auto b_tag) {
+      constexpr int b = decltype(b_tag)::value;
+      Mma<T>::run(acc[9][b], wf[9], xf[b]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (MORE1) cwp_lds_read<0>(xf[b], xa[b]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (MORE1) {
+      cwp_lds_read<9 * 16 * CB>(wf[9], wsrc);
+      cwp_lds_read_b32(hoff, aoff_addr + (unsigned)(tap1 < CW_NA ? tap1 : 0) * 2048u);      // the next item's halo piece offset
+      cwp_lds_wait_all(wf, xf, hoff);
+    }
+    pp_barrier();
+    return iss_h ? 1 : 0;
+  };
+  {
+    int tap = 0, cc = cc0, prev_h = 0;
+    unsigned hoff = hoff0;
+#pragma unroll 1
+    for (int item = 0; item + 1 < NI; ++item) {
+      prev_h = do_item(std::true_type{}, item, tap, cc, prev_h, hoff);
+      if (tap == 8) { tap = 0; ++cc; } else ++tap;
+    }
+    do_item(std::false_type{}, NI - 1, 8, cc1 - 1, prev_h, hoff);
+  }
+  if (!half) pp_barrier();
+  if (prio == 2) __builtin_amdgcn_s_setprio(0);
+  __syncthreads();   // every wave is past its last fragment read: the halo / weight LDS becomes the staging area
+  unsigned char* const slice = dsm + wave * (WIDE_STAGE_BYTES + 1280);
+  if (SK) {
+    wide_epilogue_raw(p, acc, (int)blockIdx.y, m0 + wm * 64, n0 + wn * (TN * 16), lane, slice);
+    return;
+  }
+  const float mean[TM] = {0.f, 0.f, 0.f, 0.f}, rstd[TM] = {1.f, 1.f, 1.f, 1.f};
+  wide_epilogue<T, false, RES, false>(p, acc, mean, rstd, m0 + wm * 64, n0 + wn * (TN * 16), lane, slice);
+}
+
 struct WideHaloGeom {
   int SR, nseg, halo;
 };
 
-static bool wide_halo_geom(const GemmParams& p, WideHaloGeom& g) {
+static bool wide_halo_geom(const GemmParams& p, WideHaloGeom& g, const int BM = 256) {
   const int hw = p.H * p.Wd;
-  if (p.Wd <= 0 || 256 % p.Wd != 0) return false;
-  if (hw >= 256) {
-    if (hw % 256 != 0) return false;
-    g.SR = 256 / p.Wd; g.nseg = 1;
+  if (p.Wd <= 0 || BM % p.Wd != 0) return false;
+  if (hw >= BM) {
+    if (hw % BM != 0) return false;
+    g.SR = BM / p.Wd; g.nseg = 1;
   } else {
-    if (256 % hw != 0) return false;
-    g.SR = p.H; g.nseg = 256 / hw;
+    if (BM % hw != 0) return false;
+    g.SR = p.H; g.nseg = BM / hw;
   }
   g.halo = g.nseg * (g.SR + 2) * (p.Wd + 2);
   if (!((16 % p.Wd == 0 || p.Wd % 16 == 0) && hw % 16 == 0)) return false;   // wave-uniform row-block offsets (see the kernel)
-  return g.halo <= CW_HALO_MAX;
+  return g.halo <= (BM == 512 ? CW_HALO_MAX_TALL : CW_HALO_MAX);
+}
+
+// the 512 x 160 form of the tile (TANGO_CONV_TALL): unsplit problems whose geometry fits its halo (levels 0-2 of the UNet)
+static bool conv_wide_tall_ok(const GemmParams& p) {
+  if (!tuning().conv_tall || p.splitk > 1 || p.M % 512 != 0) return false;
+  WideHaloGeom g;
+  return wide_halo_geom(p, g, 512);
 }
 
 bool conv_wide_ok(int dtype, const GemmParams& p) {
@@ -315,15 +584,33 @@ int conv_wide_pick_splitk(int dtype, const GemmParams& p) {
   return conv_wide_ok(dtype, q) ? s : 0;
 }
 
-template <typename T, bool RES, bool SK, int SCH>
+template <typename T, bool RES, bool SK, int SCH, bool TALL = false>
 static int launch_conv_wide_sch(const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {
+  constexpr int BM = TALL ? 512 : 256, BN = TALL ? 160 : 320, NA = TALL ? CW_NA_TALL : CW_NA_WIDE;
+  WideHaloGeom g;
+  if (!wide_halo_geom(p, g, BM)) TANGO_FAIL("conv_wide: unsupported geometry");
+  const int abytes = ((g.halo + 15) / 16) * 1024;
+  int lds = 2 * abytes + 4 * BN * 64 + (NA + 1) * 512 * 4;
+  const int epi_lds = 8 * (WIDE_STAGE_BYTES + 1280);
+  if (lds < epi_lds) lds = epi_lds;
+  auto kfn = conv3x3_wide_kernel<T, RES, SK, SCH, TALL>;
+  TANGO_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(kfn), lds));
+  const int tiles = (p.M / BM) * (p.N / BN);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)tiles, (unsigned)(p.splitk > 1 ? p.splitk : 1)), dim3(512), lds, s, p, zero_page, g.SR, g.nseg, abytes, tuning().wide_prio);
+  TANGO_HIP(hipGetLastError());
+  if (p.splitk > 1) TANGO_TRY(launch_splitk_reduce(TypeTag<T>::dt, p, s));
+  return 0;
+}
+
+template <typename T, bool RES, bool SK>
+static int launch_conv_wide_pipe(const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {
   WideHaloGeom g;
   if (!wide_halo_geom(p, g)) TANGO_FAIL("conv_wide: unsupported geometry");
   const int abytes = ((g.halo + 15) / 16) * 1024;
   int lds = 2 * abytes + 4 * 320 * 64 + (CW_NA + 1) * 512 * 4;
   const int epi_lds = 8 * (WIDE_STAGE_BYTES + 1280);
   if (lds < epi_lds) lds = epi_lds;
-  auto kfn = conv3x3_wide_kernel<T, RES, SK, SCH>;
+  auto kfn = conv3x3_wide_pipe_kernel<T, RES, SK>;
   TANGO_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(kfn), lds));
   const int tiles = (p.M / 256) * (p.N / 320);
   hipLaunchKernelGGL(kfn, dim3((unsigned)tiles, (unsigned)(p.splitk > 1 ? p.splitk : 1)), dim3(512), lds, s, p, zero_page, g.SR, g.nseg, abytes, tuning().wide_prio);
@@ -334,6 +621,10 @@ static int launch_conv_wide_sch(const GemmParams& p, const unsigned char* zero_p
 
 template <typename T, bool RES, bool SK = false>
 static int launch_conv_wide_cfg(const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {
+  if (tuning().wide_pipe) return launch_conv_wide_pipe<T, RES, SK>(p, zero_page, s);
+  if constexpr (!SK) {
+    if (conv_wide_tall_ok(p)) return launch_conv_wide_sch<T, RES, false, 1, true>(p, zero_page, s);
+  }
   switch (tuning().wide_sched) {
     case 0: return launch_conv_wide_sch<T, RES, SK, 0>(p, zero_page, s);
     default: return launch_conv_wide_sch<T, RES, SK, 1>(p, zero_page, s);

@@ -19,6 +19,7 @@
 // of k-chunks >= 1: the prologue issues min(nk, 3) of them).
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -245,6 +246,195 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
     t[0] = t_start; t[1] = t_first; t[2] = t_loop; t[3] = t_issued; t[4] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// In-wave software pipeline (round 6, PIPE): the same tile, ring and DMA source layout, but no read part.  The fragments of chunk
+// kc+1 are requested WHILE chunk kc is multiplied -- wf[a] is refilled in place right behind the four MFMAs that consumed it, xf[b]
+// behind its last use in column group 9 -- from inline asm (hipcc would wait lgkmcnt(0) at every use while an LDS-DMA is pending,
+// xattn.hip), and are all waited for ONCE, at the end of the item.  Both waves of a SIMD therefore always have MFMAs to issue: the
+// 60-185 cycles an LDS-DMA issue holds its wave (MI355X_MICROARCH.md) are covered by the partner's MFMAs instead of leaving the matrix
+// pipe idle, which is what the ping-pong schedule above cannot do (its partner is in its read part by construction).
+// An item is two half-items of 20 MFMAs with a raw barrier after each; the 4-wave halves run one barrier apart (half B is in
+// H1(kc-1) while half A is in H0(kc)), so a wave parked at a barrier or in the end-of-item lgkmcnt(0) has a partner in mid-stream.
+//   slot 2kc:   A H0(kc)   | B H1(kc-1)        H0(kc): groups 0-4, refills wf[0..4] from stage (kc+1)%4; then waits its own DMAs of
+//   slot 2kc+1: A H1(kc)   | B H0(kc)                  chunk kc+2 (chunk kc+3 stays in flight)
+//                                              H1(kc): groups 5-9, refills wf[5..9] / xf[0..3]; issues chunk kc+4 into stage kc%4;
+//                                                      lgkmcnt(0)
+// Stage kc%4 (chunk kc) is read by A in slots 2kc-2, 2kc-1 and by B in slots 2kc-1, 2kc, all reads returned by the barrier that ends
+// slot 2kc (B's end-of-item lgkmcnt(0)); it is overwritten from slot 2kc+1 on.  Chunk kc+2 is first read in slot 2kc+2 (A's
+// H0(kc+1)); every wave has waited for its own pieces of it by the end of its H0(kc) (A: slot 2kc, B: slot 2kc+1), one barrier earlier.
+// Same MFMA order per accumulator as gemm_wide_kernel: bit-identical results.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int OFF> __device__ __forceinline__ void wp_lds_read(u32x4& v, const unsigned base) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(OFF));
+}
+// every fragment read issued so far has returned; ties the 14 fragments to the wait (no consumer can be scheduled above it)
+__device__ __forceinline__ void wp_lds_wait_all(u32x4 (&wf)[10], u32x4 (&xf)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(wf[4]), "+v"(wf[5]), "+v"(wf[6]), "+v"(wf[7]), "+v"(wf[8]), "+v"(wf[9]),
+                 "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]));
+}
+template <int I, int N, typename F> __device__ __forceinline__ void wp_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); wp_for<I + 1, N>(f); }
+}
+
+template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool XS>
+__global__ __launch_bounds__(512) void gemm_wide_pipe_kernel(const GemmParams p, const int prio) {
+  constexpr int BM = 256, BN = 320, CB = 64, NST = 4;
+  constexpr int ROWS = BM + BN, STAGE = ROWS * CB;
+  constexpr int RG = ROWS / 16, RGW = (RG + 7) / 8;
+  constexpr int TM = 4, TN = 10;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+
+  const int NT = p.N / BN;
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (bid / NT) * BM, n0 = (bid % NT) * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2, half = wave >> 2;
+
+  const int lrow = lane >> 2;
+  const int pc = (lane & 3) ^ ((4 - (lrow >> 2)) & 3);
+  const unsigned char* const At = (const unsigned char*)p.A + (int64_t)m0 * p.lda * (int64_t)sizeof(T);
+  const unsigned char* const Wt = (const unsigned char*)p.W + (int64_t)n0 * p.Kp * (int64_t)sizeof(T);
+  unsigned r_off[RGW];
+#pragma unroll
+  for (int i = 0; i < RGW; ++i) {
+    const int row = (wave + 8 * i) * 16 + lrow;
+    r_off[i] = i < 2 ? (unsigned)((int64_t)row * p.lda * (int64_t)sizeof(T)) + pc * 16
+                     : (unsigned)((int64_t)(row - BM) * p.Kp * (int64_t)sizeof(T)) + pc * 16;
+  }
+  const int nk = (p.K * (int)sizeof(T)) / CB;            // >= NST (launcher)
+  const bool has5 = wave < RG - 8 * (RGW - 1);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
+  auto dma = [&](const int i, const unsigned char* sa, const unsigned char* sw, const unsigned ldst) {
+    unsigned o = r_off[i];
+    asm volatile("" : "+v"(o));
+    __builtin_amdgcn_global_load_lds((gptr_t)((i < 2 ? sa : sw) + o), (lptr_t)(uintptr_t)(ldst + (unsigned)i * 8192u), 16, 0, 0);
+  };
+  auto issue_chunk = [&](const int kc) {
+    const unsigned char* sa = At + (int64_t)kc * CB;
+    const unsigned char* sw = Wt + (int64_t)kc * CB;
+#pragma unroll
+    for (int i = 0; i < RGW; ++i)
+      if (i < RGW - 1 || has5) dma(i, sa, sw, lds0 + (kc & (NST - 1)) * STAGE + (unsigned)wave * 1024u);
+  };
+  // at most `chunks` (0..2) whole chunks of this wave's DMAs may stay in flight
+  auto wait_inflight = [&](const int chunks) {
+    if (chunks <= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+    if (has5) {
+      if (chunks == 1) wait_vmcnt_lit<RGW>();
+      else wait_vmcnt_lit<2 * RGW>();
+    } else {
+      if (chunks == 1) wait_vmcnt_lit<RGW - 1>();
+      else wait_vmcnt_lit<2 * (RGW - 1)>();
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float ssum[TM] = {0.f, 0.f, 0.f, 0.f}, ssq[TM] = {0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, g = lane >> 4;
+  const int foff = l15 * CB + ((g ^ ((4 - (l15 >> 2)) & 3)) * 16);
+  const unsigned xrow = lds0 + (unsigned)((wm * TM * 16) * CB + foff);
+  const unsigned wrow = lds0 + (unsigned)((BM + wn * TN * 16) * CB + foff);
+
+  for (int c = 0; c < NST; ++c) issue_chunk(c);
+  wait_inflight(2);                                     // chunks 0 and 1 landed
+  pp_barrier();
+  u32x4 wf[TN], xf[TM];
+  wp_for<0, TN>([&](auto a) { wp_lds_read<a * 16 * CB>(wf[a], wrow); });
+  wp_for<0, TM>([&](auto b) { wp_lds_read<b * 16 * CB>(xf[b], xrow); });
+  wp_lds_wait_all(wf, xf);
+  __builtin_amdgcn_sched_barrier(0);
+  if (half) pp_barrier();                               // the stagger
+  if (prio == 2 && half) __builtin_amdgcn_s_setprio(1);
+  // one item; MORE1: chunk kc+1 exists (refill the fragments) -- compile-time, the last item is peeled
+  auto item = [&](auto more1_tag, const int kc) __attribute__((always_inline)) {
+    constexpr bool MORE1 = decltype(more1_tag)::value;
+    const bool more4 = kc + NST < nk;                   // chunk kc+4 exists: DMA into the stage of chunk kc
+    const bool more45 = more4 && has5;
+    const unsigned st1 = (unsigned)((kc + 1) & (NST - 1)) * STAGE;
+    unsigned wsrc = wrow + st1, xsrc = xrow + st1;
+    asm volatile("" : "+v"(wsrc), "+v"(xsrc));
+    const unsigned char* sa = At + (int64_t)(kc + NST) * CB;
+    const unsigned char* sw = Wt + (int64_t)(kc + NST) * CB;
+    const unsigned ldst = lds0 + (unsigned)(kc & (NST - 1)) * STAGE + (unsigned)wave * 1024u;
+    if (LN && !XS) {
+#pragma unroll
+      for (int b = 0; b < TM; ++b) wide_frag_stats<T>(xf[b], ssum[b], ssq[b]);
+    }
+    // ---- H0: column groups 0-4 ----
+    wp_for<0, 5>([&](auto a_tag) {
+      constexpr int a = decltype(a_tag)::value;
+#pragma unroll
+      for (int b = 0; b < TM; ++b) Mma<T>::run(acc[a][b], wf[a], xf[b]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (MORE1) wp_lds_read<a * 16 * CB>(wf[a], wsrc);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (kc + 2 < nk) wait_inflight(kc + 3 < nk ? 1 : 0);
+    pp_barrier();
+    // ---- H1: column groups 5-9, the DMAs of chunk kc+4 ----
+    wp_for<5, 9>([&](auto a_tag) {
+      constexpr int a = decltype(a_tag)::value;
+#pragma unroll
+      for (int b = 0; b < TM; ++b) Mma<T>::run(acc[a][b], wf[a], xf[b]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (MORE1) wp_lds_read<a * 16 * CB>(wf[a], wsrc);
+      if (more4) dma(a - 5, sa, sw, ldst);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    wp_for<0, TM>([&](auto b_tag) {
+      constexpr int b = decltype(b_tag)::value;
+      Mma<T>::run(acc[9][b], wf[9], xf[b]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (MORE1) wp_lds_read<b * 16 * CB>(xf[b], xsrc);
+      if (b == 1 && more45) dma(4, sa, sw, ldst);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (MORE1) {
+      wp_lds_read<9 * 16 * CB>(wf[9], wsrc);
+      wp_lds_wait_all(wf, xf);
+    }
+    pp_barrier();
+  };
+  for (int kc = 0; kc + 1 < nk; ++kc) item(std::true_type{}, kc);
+  item(std::false_type{}, nk - 1);
+  if (!half) pp_barrier();
+  if (prio == 2) __builtin_amdgcn_s_setprio(0);
+  __syncthreads();   // every wave is past its last fragment read: the operand stages become the staging area
+  float mean[TM] = {0.f, 0.f, 0.f, 0.f}, rstd[TM] = {1.f, 1.f, 1.f, 1.f};
+  if (LN && XS) {
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      const f32x2 sv = *(const f32x2*)(p.row_stats + (int64_t)(m0 + wm * TM * 16 + b * 16 + (lane & 15)) * 2);
+      mean[b] = sv.x; rstd[b] = sv.y;
+    }
+  } else if (LN) {
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      float sm = ssum[b], sq = ssq[b];
+      sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+      sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+      const float mu = sm / (float)p.K;
+      float var = sq / (float)p.K - mu * mu;
+      var = var < 0.f ? 0.f : var;
+      mean[b] = mu; rstd[b] = rsqrtf(var + p.ln_eps);
+    }
+  }
+  unsigned char* const slice = dsm + wave * (WIDE_STAGE_BYTES + 1280);
+  if (VT && n0 >= p.vt_n0) wide_epilogue_vt<T, LN>(p, acc, mean, rstd, m0 + wm * TM * 16, n0 + wn * TN * 16, lane, slice);
+  else wide_epilogue<T, GEGLU, RES, LN>(p, acc, mean, rstd, m0 + wm * TM * 16, n0 + wn * TN * 16, lane, slice);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -545,7 +735,40 @@ static int launch_wide_t(const GemmParams& p, hipStream_t s) {
   return p.R ? launch_wide_cfg<T, false, true, false>(p, s) : launch_wide_cfg<T, false, false, false>(p, s);
 }
 
+template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool XS>
+static int launch_wide_pipe_cfg(const GemmParams& p, hipStream_t s) {
+  constexpr int LDS = 4 * (256 + 320) * 64;
+  auto kfn = gemm_wide_pipe_kernel<T, GEGLU, RES, LN, VT, XS>;
+  TANGO_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(kfn), LDS));
+  const unsigned grid = (unsigned)((p.M / 256) * (p.N / 320));
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS, s, p, tuning().wide_prio);
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+// the in-wave software pipeline (TANGO_WIDE_PIPE): the epilogue kinds the persistent form has, K >= 4 chunks
+template <typename T>
+static int launch_wide_pipe_t(const GemmParams& p, hipStream_t s, bool& taken) {
+  taken = true;
+  if (p.row_stats) return launch_wide_pipe_cfg<T, true, false, true, false, true>(p, s);
+  if (p.epi == EPI_VT) return p.ln_fold ? launch_wide_pipe_cfg<T, false, false, true, true, false>(p, s) : launch_wide_pipe_cfg<T, false, false, false, true, false>(p, s);
+  if (p.epi == EPI_GEGLU) {
+    if (!p.R && !p.ln_fold) return launch_wide_pipe_cfg<T, true, false, false, false, false>(p, s);
+    taken = false;
+    return 0;
+  }
+  if (p.ln_fold) return p.R ? launch_wide_pipe_cfg<T, false, true, true, false, false>(p, s) : launch_wide_pipe_cfg<T, false, false, true, false, false>(p, s);
+  return p.R ? launch_wide_pipe_cfg<T, false, true, false, false, false>(p, s) : launch_wide_pipe_cfg<T, false, false, false, false, false>(p, s);
+}
+
 int launch_gemm_wide(int dtype, const GemmParams& p, hipStream_t s) {
+  if (tuning().wide_pipe && p.splitk <= 1 && p.K * 2 >= 4 * 64) {
+    bool taken = false;
+    int rc = 0;
+    if (dtype == DT_F16) rc = launch_wide_pipe_t<f16>(p, s, taken);
+    else if (dtype == DT_BF16) rc = launch_wide_pipe_t<bf16>(p, s, taken);
+    if (taken) return rc;
+  }
   const int pers = tuning().wide_pers;
   if (pers > 0 && p.splitk <= 1 && (long)(p.M / 256) * (p.N / 320) >= (long)pers * wide_pers_grid(1L << 30)) {
     bool taken = false;

@@ -42,6 +42,8 @@ struct Tuning {
   int duo_min_tiles;        // TANGO_DUO_MIN_TILES=n    ... that have at least n tiles of 256 x 160
   int duo_mask;             // TANGO_DUO_MASK=bits      ... of these classes: 1 plain, 2 GEGLU, 4 folded LayerNorm (incl. transposed V), 8 folded LayerNorm + GEGLU
   int duo_prio;             // TANGO_DUO_PRIO=0..1      0 = s_setprio 1 around its MFMAs, 1 = no priority changes
+  int conv_tall;            // TANGO_CONV_TALL=0|1      3x3 wide conv on the 512-pixel x 160-channel form of the tile where the halo fits (round 6: half the weight DMA per MFMA)
+  int wide_pipe;            // TANGO_WIDE_PIPE=0|1      256 x 320 GEMM / conv: in-wave software pipeline (fragments of item i+1 requested under the MFMAs of item i) instead of the ping-pong read / multiply parts (round 6)
 };
 
 inline Tuning read_tuning() {
@@ -77,6 +79,8 @@ inline Tuning read_tuning() {
   x.duo_min_tiles = num("TANGO_DUO_MIN_TILES", 384);
   x.duo_mask = num("TANGO_DUO_MASK", 7);
   x.duo_prio = num("TANGO_DUO_PRIO", 0);
+  x.wide_pipe = num("TANGO_WIDE_PIPE", 0);
+  x.conv_tall = num("TANGO_CONV_TALL", 0);
   const char* wp = getenv("TANGO_WIDE_PRIO");
   x.wide_prio = (wp && wp[0] >= '0' && wp[0] <= '2') ? wp[0] - '0' : 0;
   return x;

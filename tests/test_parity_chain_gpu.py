@@ -1,0 +1,120 @@
+"""End-to-end chain parity in the DEFAULT GPU suite (VERDICT r5 "next round" item 8): the 16-bit engine's latents after a multi-step
+CFG loop go straight into `vae_decode` -> `vocode`, and latents / mel / int16 waveform are compared with the fp32 CPU oracle run on
+the same inputs (reference path: models.py:224-249 -> audioldm/variational_autoencoder/autoencoder.py:116-124,66-69).
+
+  (a) B = 2 prompts, 20 DDPM steps with injected noise, fp16 engine: the pieces test_parity_batch_gpu.py / test_parity_full_gpu.py
+      check separately, chained;
+  (b) B = 1, 50 DDPM steps: half of BASELINE config 2's length against the ORACLE (the 100 / 200-step ladder stays opt-in in
+      test_parity_long_gpu.py: minutes of host time).
+
+Floors are REQUIREMENTS, not multiples of what was measured: a drop-in in 16-bit storage must deliver
+  fp16:  latents max abs err <= 5e-2 (|latents| ~ 5),  mel PSNR >= 65 dB,  waveform SNR >= 40 dB
+  bf16:  (test_parity_batch_gpu.py)                    mel PSNR >= 50 dB,  waveform SNR >= 25 dB
+With TANGO_WRITE_PARITY_RECORD=<file> the measured ladder is written as JSON (committed as profiles/parity_ladder.json; bench.py
+quotes it in its `parity` object next to the throughput it belongs to)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import tango_oracle as O  # noqa: E402  (checker only)
+from tango_amd import weights as W  # noqa: E402
+from tango_amd.engine import Engine  # noqa: E402
+from tango_amd.scheduler import SD21_SCHEDULER_CONFIG, DDPMScheduler  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+_KEYS = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "prediction_type", "clip_sample", "variance_type")
+FP16_LATENT_MAX_ABS, FP16_MEL_PSNR_DB, FP16_WAVE_SNR_DB = 5e-2, 65.0, 40.0
+
+
+def _psnr(x, ref):
+    mse = ((x.double() - ref.double()) ** 2).mean().item()
+    peak = (ref.max() - ref.min()).item()
+    return 10 * np.log10(peak * peak / (mse + 1e-30))
+
+
+def _snr(x, ref):
+    x, ref = x.astype(np.float64), ref.astype(np.float64)
+    return 10 * np.log10((ref ** 2).mean() / (((x - ref) ** 2).mean() + 1e-30))
+
+
+def _record(key, rec):
+    path = os.environ.get("TANGO_WRITE_PARITY_RECORD")
+    if not path:
+        return
+    try:
+        cur = json.load(open(path))
+    except (OSError, ValueError):
+        cur = {}
+    cur[key] = rec
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    json.dump(cur, open(path, "w"), indent=1, sort_keys=True)
+
+
+def _chain(B, N, dtype, seed):
+    L = 64
+    g = torch.Generator().manual_seed(seed)
+    cond = torch.randn(B, L, 1024, generator=g)
+    unc = torch.randn(B, L, 1024, generator=g)
+    enc = torch.cat([unc, cond])
+    mask = torch.ones(2 * B, L, dtype=torch.bool)
+    mask[:B, 1:] = False                                   # T5(""): one valid token (models.py:282-289)
+    if B > 1:
+        mask[B + 1, 40:] = False                           # a ragged conditional prompt
+    lat0 = torch.randn(B, 8, 256, 16, generator=g)
+    noises = torch.randn(N, B, 8, 256, 16, generator=g)
+    sd = W.synth_state_dict(W.unet_param_shapes(O.UNET_CONFIG_LARGE, "unet."), 1234)
+    shapes = W.vae_decoder_param_shapes(O.VAE_CONFIG)
+    shapes.update(W.hifigan_param_shapes(O.HIFIGAN_CONFIG))
+    vsd = W.synth_state_dict(shapes, 1234)
+    # engine first (seconds), oracle second (the host-bound part)
+    e = Engine(unet=O.UNET_CONFIG_LARGE, dtype=dtype)
+    e.load_synthetic(1234)
+    sch = DDPMScheduler.from_config({k: SD21_SCHEDULER_CONFIG[k] for k in _KEYS})
+    sch.set_timesteps(N)
+    lat = lat0.clone().cuda()
+    e.denoise(lat, enc.cuda(), mask.cuda(), sch.timesteps.numpy(), sch.coef_table(), 3.0, noise=noises.cuda())
+    torch.cuda.synchronize()
+    del e
+    ev = Engine(vae=O.VAE_CONFIG, hifigan=O.HIFIGAN_CONFIG, dtype=dtype)
+    ev.load_synthetic(1234)
+    mel = ev.vae_decode(lat)                               # the ENGINE's latents, not the oracle's: errors compound as in production
+    wav = ev.vocode(mel).cpu().numpy()
+    del ev
+    with torch.no_grad():
+        rlat = O.denoise_loop(sd, O.UNET_CONFIG_LARGE, O.DDPMOracle(**O.SD21_SCHEDULER), enc, mask, lat0.clone(), N, 3.0, noises=list(noises),
+                              prefix="unet.")
+        rmel = O.vae_decode_first_stage(vsd, O.VAE_CONFIG, rlat)
+        rwav = O.decode_to_waveform(vsd, O.HIFIGAN_CONFIG, rmel)
+    rwav = np.asarray(rwav)
+    assert wav.dtype == np.int16 and wav.shape == rwav.shape == (B, 163872)
+    lat, mel = lat.cpu(), mel.cpu()
+    rec = {"batch": B, "denoise_steps": N, "dtype": dtype, "guidance": 3.0,
+           "latents_max_abs_err": (lat - rlat).abs().max().item(), "latents_abs_max": rlat.abs().max().item(),
+           "mel_psnr_db": min(_psnr(mel[i], rmel[i]) for i in range(B)),
+           "wave_snr_db": min(_snr(wav[i], rwav[i]) for i in range(B)),
+           "lsb1_frac": float((np.abs(wav.astype(np.int32) - rwav.astype(np.int32)) <= 1).mean()),
+           "int16_max_abs_diff": int(np.abs(wav.astype(np.int32) - rwav.astype(np.int32)).max())}
+    print("chain B=%d, %d DDPM steps, %s engine vs fp32 oracle: latents max abs err %.3e (|ref| max %.2f), mel PSNR %.1f dB, waveform SNR "
+          "%.1f dB, int16 within 1 LSB on %.4f (max |diff| %d)" % (B, N, dtype, rec["latents_max_abs_err"], rec["latents_abs_max"],
+                                                                  rec["mel_psnr_db"], rec["wave_snr_db"], rec["lsb1_frac"], rec["int16_max_abs_diff"]))
+    return rec
+
+
+def test_chain_b2_20step_fp16_against_the_oracle():
+    rec = _chain(2, 20, "fp16", 404)
+    _record("fp16_b2_20step_chain", rec)
+    assert rec["latents_max_abs_err"] <= FP16_LATENT_MAX_ABS
+    assert rec["mel_psnr_db"] >= FP16_MEL_PSNR_DB and rec["wave_snr_db"] >= FP16_WAVE_SNR_DB
+
+
+def test_chain_b1_50step_fp16_against_the_oracle():
+    rec = _chain(1, 50, "fp16", 505)
+    _record("fp16_b1_50step_chain", rec)
+    assert rec["latents_max_abs_err"] <= FP16_LATENT_MAX_ABS
+    assert rec["mel_psnr_db"] >= FP16_MEL_PSNR_DB and rec["wave_snr_db"] >= FP16_WAVE_SNR_DB

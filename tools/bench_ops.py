@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmark of single engine ops through the C ABI (for rocprofv3 --pmc runs).
-usage: python tools/bench_ops.py linear M N K [reps [res|nores [geglu]]]   |   conv B C H W Cout [reps]
+usage: python tools/bench_ops.py linear M N K [reps [res|nores [geglu]]]   |   conv B C H W Cout [reps [randn|zeros|ones]]
        python tools/bench_ops.py linear_ln M N K [reps [geglu]]      (LayerNorm folded into the projection: tango_op_linear_ln)"""
 import ctypes as C
 import os
@@ -41,8 +41,10 @@ elif kind == "linear_ln":
 elif kind == "conv":
     B, Cc, H, W, Co = [int(v) for v in sys.argv[2:7]]
     reps = int(sys.argv[7]) if len(sys.argv) > 7 else 5
-    x = torch.randn(B, Cc, H, W, device="cuda")
-    w = torch.randn(Co, Cc, 3, 3, device="cuda") / (9 * Cc) ** 0.5
+    fill = sys.argv[8] if len(sys.argv) > 8 else "randn"      # randn | zeros | ones: the DVFS regime probe (MI355X_MICROARCH.md: zero-filled operands clock higher)
+    mk = {"randn": torch.randn, "zeros": torch.zeros, "ones": torch.ones}[fill]
+    x = mk(B, Cc, H, W, device="cuda")
+    w = mk(Co, Cc, 3, 3, device="cuda") / (9 * Cc) ** 0.5
     b = torch.randn(Co, device="cuda")
     out = torch.empty(B, Co, H, W, device="cuda")
     for _ in range(reps):
