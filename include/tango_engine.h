@@ -217,6 +217,11 @@ int tango_engine_plan_stats(tango_engine_t* h, uint64_t* bytes_in_use, int* plan
 int tango_engine_drop_plans(tango_engine_t* h);
 
 int tango_engine_profile_unet(tango_engine_t* h, int batch2, int text_len, char* report, int report_cap, void* stream);
+/* the same per-op table ("label\tms\tGFLOP" lines, HIP events around every op of the eager plan) for the two stages that follow the
+ * denoise loop in every pass: the mel-VAE decoder (audioldm/variational_autoencoder/modules.py:546-683, autoencoder.py:116-124) for
+ * `batch` latents, and HiFi-GAN (audioldm/hifigan/models.py:96-165) for `batch` mels of `frames` frames.  Measurement tools only. */
+int tango_engine_profile_vae(tango_engine_t* h, int batch, char* report, int report_cap, void* stream);
+int tango_engine_profile_vocoder(tango_engine_t* h, int batch, int frames, char* report, int report_cap, void* stream);
 /* measurement tools only: re-read the TANGO_* dispatch switches (csrc/tuning.h) from the environment, so that one process can
  * time several arms of an A/B back to back (tools/profile_unet_ops.py --ab).  No reference counterpart. */
 void tango_tuning_reload(void);

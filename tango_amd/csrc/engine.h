@@ -204,6 +204,8 @@ class Engine {
   int mel_spectrogram(const float* wav, float* mel, float* logmag, float* energy, int B, int N, int* n_frames, hipStream_t s);
   int last_denoise_ms(float* total_ms, float* per_step_ms);
   int profile_unet(int B2, int L, std::string& report, hipStream_t s);
+  int profile_vae(int B, std::string& report, hipStream_t s);                  // per-op timing of the mel-VAE decoder plan (round 6)
+  int profile_vocoder(int B, int frames, std::string& report, hipStream_t s);  // ... of the HiFi-GAN plan
   // plan-cache budget (bytes of workspace slabs kept alive; default 64 GiB or TANGO_PLAN_BUDGET_MB) and its current use
   void set_plan_budget(size_t bytes) { plan_budget = bytes; }
   void drop_plans() { const size_t b = plan_budget; plan_budget = 0; (void)make_room(1); plan_budget = b; }   // frees every cached plan

@@ -942,6 +942,9 @@ int Engine::init() {
   }
   if (cfg.voc_n_ups > 0) build_voc_weights();
   if (cfg.t5_layers > 0) {
+    // FLAN-T5 hidden states exceed the fp16 range, and the 16-bit tile epilogues carry the exact-erf gate only (the T5 feed-forward
+    // is gated tanh-GELU): refuse here, by name, instead of at the first encode_text
+    if (dt != DT_F32) TANGO_FAIL("engine: the FLAN-T5 text encoder runs on an fp32 engine only (dtype must be fp32 when a t5 config is given)");
     if (cfg.t5_d_kv != 64) TANGO_FAIL("engine: T5 d_kv must be 64 (attention head_dim)");
     if (cfg.t5_d_model % 16 || cfg.t5_d_ff % 16) TANGO_FAIL("engine: T5 d_model / d_ff must be multiples of 16");
     build_t5_weights();
@@ -1525,6 +1528,25 @@ int Engine::profile_unet(int B2, int L, std::string& report, hipStream_t s) {
   return P->step.run_profiled(s, report);
 }
 
+// per-op tables of the two plans that follow the denoise loop in every pass (they had no per-op profile); inputs
+// are whatever the plan buffers hold -- only the times matter
+int Engine::profile_vae(int B, std::string& report, hipStream_t s) {
+  if (cfg.vae_levels <= 0) TANGO_FAIL("engine: VAE not configured");
+  VaePlan* P;
+  TANGO_TRY(get_vae_plan(B, &P));
+  TANGO_TRY(P->prog.run(s));
+  TANGO_HIP(hipStreamSynchronize(s));
+  return P->prog.run_profiled(s, report);
+}
+int Engine::profile_vocoder(int B, int frames, std::string& report, hipStream_t s) {
+  if (cfg.voc_n_ups <= 0) TANGO_FAIL("engine: vocoder not configured");
+  VaePlan* P;
+  TANGO_TRY(get_voc_plan(B, frames, &P));
+  TANGO_TRY(P->prog.run(s));
+  TANGO_HIP(hipStreamSynchronize(s));
+  return P->prog.run_profiled(s, report);
+}
+
 int Engine::last_denoise_ms(float* total_ms, float* per_step_ms) {
   if (last_steps <= 0) TANGO_FAIL("last_denoise_ms: no denoise call recorded");
   TANGO_HIP(hipEventSynchronize(ev1));
@@ -1534,11 +1556,15 @@ int Engine::last_denoise_ms(float* total_ms, float* per_step_ms) {
   if (per_step_ms) *per_step_ms = ms / (float)last_steps;
   // the work is complete here.  A cooperative kernel whose partners did not all show up in time (norm.hip gn_coop_kernel: the GPU was
   // shared) recomputed the missing partial sums itself -- same bits, only slower -- and counted it: report once per occurrence, reset
-  unsigned n = 0;
-  TANGO_HIP(hipMemcpy(&n, d_sync + 2 * COOP_SYNC_SLOTS, 4, hipMemcpyDeviceToHost));
+  // (both chains' counter words: TANGO_UNET_CHAINS=2 runs the second half-batch chain on d_sync2)
+  unsigned n1 = 0, n2 = 0;
+  TANGO_HIP(hipMemcpy(&n1, d_sync + 2 * COOP_SYNC_SLOTS, 4, hipMemcpyDeviceToHost));
+  TANGO_HIP(hipMemcpy(&n2, d_sync2 + 2 * COOP_SYNC_SLOTS, 4, hipMemcpyDeviceToHost));
+  if (n1) TANGO_HIP(hipMemset(d_sync + 2 * COOP_SYNC_SLOTS, 0, 4));
+  if (n2) TANGO_HIP(hipMemset(d_sync2 + 2 * COOP_SYNC_SLOTS, 0, 4));
+  const unsigned n = n1 + n2;
   if (n) {
     coop_fallbacks += n;
-    TANGO_HIP(hipMemset(d_sync + 2 * COOP_SYNC_SLOTS, 0, 4));
     if (!tuning().gn_coop_force_fb)
       fprintf(stderr, "tango: %u workgroup(s) of the cooperative GroupNorm took the no-rendezvous fallback (GPU shared with other work?); "
                       "results are unaffected, TANGO_NO_GN_COOP=1 avoids the slow path\n", n);
@@ -2099,6 +2125,22 @@ int tango_engine_profile_unet(tango_engine_t* h, int batch2, int text_len, char*
     report[n] = 0;
   }
   return rc;
+}
+int tango_engine_profile_vae(tango_engine_t* h, int batch, char* report, int report_cap, void* stream) {
+  if (!h || !report || report_cap <= 0) { tango::set_error("tango_engine_profile_vae: null argument"); return -1; }
+  std::string r;
+  int rc = h->e->profile_vae(batch, r, (hipStream_t)stream);
+  if (rc) return rc;
+  snprintf(report, (size_t)report_cap, "%s", r.c_str());
+  return 0;
+}
+int tango_engine_profile_vocoder(tango_engine_t* h, int batch, int frames, char* report, int report_cap, void* stream) {
+  if (!h || !report || report_cap <= 0) { tango::set_error("tango_engine_profile_vocoder: null argument"); return -1; }
+  std::string r;
+  int rc = h->e->profile_vocoder(batch, frames, r, (hipStream_t)stream);
+  if (rc) return rc;
+  snprintf(report, (size_t)report_cap, "%s", r.c_str());
+  return 0;
 }
 
 int tango_engine_last_denoise_ms(tango_engine_t* h, float* total_ms, float* per_step_ms) {

@@ -156,8 +156,11 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
   int grp = g0 + wave;
   const unsigned char* cur[TM];
   const unsigned char* nxt[TM];
+  // (a wave -- or a whole workgroup, when ngroups is not a multiple of MB: g0 >= ngroups -- without a row group still issues this
+  //  prefetch; SPEC = 1 has no per-row clamp, so the GROUP is clamped into the tensor: ADVICE r5)
+  const int g_safe = g0 < ngroups ? g0 : ngroups - 1;
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm) cur[tm] = row_ptr_c(grp < g1 ? grp : g0, tm);
+  for (int tm = 0; tm < TM; ++tm) cur[tm] = row_ptr_c(grp < g1 ? grp : g_safe, tm);
 #pragma unroll
   for (int s = 0; s < R; ++s)
 #pragma unroll

@@ -48,6 +48,10 @@ template <typename T> static GnGeom gn_geom(int B, int rows, int C) {
   long total = (long)rows * B;
   int rc = (int)((total + 2047) / 2048);
   if (rc < 16) rc = 16;
+  // at most 256 chunks per sample: gn_apply folds the finalize step in, i.e. EVERY workgroup re-reduces all `chunks` partials of its
+  // sample -- O(chunks^2) bytes per sample.  The VAE's 65536-row tensors at B = 1 had 2048 chunks of 32 rows: 241 us per GroupNorm
+  // (1.45 of the 3.6-ms B = 1 decode, profiles/r6_c4_vae_vocoder_per_op_b1.txt); UNet shapes and B >= 8 are unaffected (<= 256 already)
+  if (rc < (rows + 255) / 256) rc = (rows + 255) / 256;
   rc = ((rc + g.RPB - 1) / g.RPB) * g.RPB;
   if (rc > rows) rc = ((rows + g.RPB - 1) / g.RPB) * g.RPB;
   g.RC = rc;

@@ -1,5 +1,6 @@
 """Thin Python handle over the C-ABI engine.  PyTorch is plumbing only: device memory, streams."""
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -272,6 +273,13 @@ class Engine:
             if prompt_mask_host.is_cuda or tuple(prompt_mask_host.shape) != tuple(prompt_mask.shape):
                 raise ValueError("prompt_mask_host must be a CPU tensor of prompt_mask's shape %s" % (tuple(prompt_mask.shape),))
             mask_host = prompt_mask_host.to(torch.uint8).contiguous()
+            # ONE source of truth: the plan (single-key prefix, CFG-shared prefix) is picked from the host copy and the
+            # attention kernels read the device mask, so the device mask is re-derived from the host copy here (a 2B x L byte upload,
+            # asynchronous: still no host sync) instead of trusting that the caller's two copies are identical.
+            # TANGO_DEBUG_MASK=1 additionally compares the caller's device mask with it (one D2H + sync) and fails on a difference.
+            if os.environ.get("TANGO_DEBUG_MASK") and not torch.equal(mask.cpu(), mask_host):
+                raise ValueError("prompt_mask_host differs from the device prompt_mask")
+            mask = mask_host.to(self.device, non_blocking=True)
         rows = 2 * latents.shape[0] if guidance_scale > 1.0 else latents.shape[0]
         self._check_cond("prompt_embeds", enc, mask, rows)
         ts = np.ascontiguousarray(np.asarray(timesteps, dtype=np.int64))
@@ -325,6 +333,24 @@ class Engine:
             lab, ms, gf = line.rsplit("\t", 2)
             rows.append((lab, float(ms), float(gf)))
         return rows
+
+    def _profile(self, fn, what, *args):
+        buf = C.create_string_buffer(1 << 20)
+        with torch.cuda.device(self.device):
+            _lib.check(fn(self._h, *args, buf, len(buf), _stream_ptr()), what)
+        rows = []
+        for line in buf.value.decode().splitlines():
+            lab, ms, gf = line.rsplit("\t", 2)
+            rows.append((lab, float(ms), float(gf)))
+        return rows
+
+    def profile_vae(self, batch: int):
+        """per-op timing of the mel-VAE decoder plan for `batch` latents: list of (label, ms, gflop)"""
+        return self._profile(self.lib.tango_engine_profile_vae, "profile_vae", int(batch))
+
+    def profile_vocoder(self, batch: int, frames: int = 1024):
+        """per-op timing of the HiFi-GAN plan for `batch` mels of `frames` frames: list of (label, ms, gflop)"""
+        return self._profile(self.lib.tango_engine_profile_vocoder, "profile_vocoder", int(batch), int(frames))
 
     def set_plan_budget(self, nbytes: int):
         """byte budget of the plan cache (workspace slabs kept alive per call shape); least recently used plans are freed first"""

@@ -11,6 +11,7 @@ Step noise is keyed by (seed, GLOBAL sample index): rank 0 draws ONE seed per ba
 header, so results do not depend on the number of ranks and no per-rank call counter can drift.
 """
 import os
+import time
 from typing import Callable, List, Optional, Sequence, Tuple
 
 # dmabuf IPC: the host driver of this platform supports no legacy IPC handles, and without this RCCL's intra-node transports fail with
@@ -49,10 +50,15 @@ class DataParallelGenerator:
     """compute(embeds_local, mask_local, sample_offset, seed) -> int16 [b_local, n_samples]
     (a torch tensor on `device` -- it is gathered without leaving the device -- or a numpy array)."""
 
-    def __init__(self, compute: Callable, device: torch.device, group=None):
+    def __init__(self, compute: Callable, device: torch.device, group=None, timing: bool = False):
         self.compute = compute
         self.device = torch.device(device)
         self.group = group
+        # `timing` (bench.py): every pass records the wall time of its three stages in `self.last_timing` -- header + embedding
+        # broadcast, this rank's compute, waveform gather -- with a device synchronisation at each stage boundary, so that a
+        # scaling run shows a straggler rank or a slow collective instead of one number.  Off on the product path (no extra syncs).
+        self.timing = timing
+        self.last_timing = None
         # `collective`: a process group exists, so every exchange below goes through it -- also at world size 1, which is how the RCCL
         # calls of this file (int64 / fp32 / uint8 broadcast, byte gather) are exercised on a one-GPU box (tests/test_parallel_nccl_gpu.py)
         self.collective = dist.is_initialized()
@@ -78,6 +84,7 @@ class DataParallelGenerator:
         slot where rank 0 tokenises / encodes the NEXT pass (generate_for_batch_dp), hidden behind this pass's denoise.
         Returns the global int16 waveforms [B, n_samples] on rank 0, None elsewhere."""
         cfg_on = guidance > 1.0
+        t_start = self._stamp()
         hdr = torch.zeros(4, dtype=torch.int64, device=self.device)
         if self.rank == 0:
             if seed is None:
@@ -92,6 +99,7 @@ class DataParallelGenerator:
         pe_l, pm_l, lo = shard_cfg_embeddings(pe, pm.bool(), self.world, self.rank, cfg_on)
         b_local = pe_l.shape[0] // 2 if cfg_on else pe_l.shape[0]
         wav = None
+        t_bcast = self._stamp()
         if b_local > 0:
             wav = self.compute(pe_l, pm_l, lo, seed)
             if isinstance(wav, np.ndarray):
@@ -99,8 +107,11 @@ class DataParallelGenerator:
             assert wav.dtype == torch.int16 and tuple(wav.shape) == (b_local, n_samples), (wav.dtype, tuple(wav.shape))
         if after_compute is not None:
             after_compute()
+        t_comp = self._stamp()
         if not self.collective:
-            return wav.cpu().numpy() if wav is not None else np.zeros((0, n_samples), np.int16)
+            out = wav.cpu().numpy() if wav is not None else np.zeros((0, n_samples), np.int16)
+            self._record(t_start, t_bcast, t_comp, self._stamp(), b_local)
+            return out
         bmax = (B + self.world - 1) // self.world
         buf = torch.zeros((bmax, n_samples), dtype=torch.int16, device=self.device)
         if wav is not None:
@@ -110,16 +121,47 @@ class DataParallelGenerator:
         outs8 = [torch.empty_like(raw) for _ in range(self.world)] if self.rank == 0 else None
         dist.gather(raw, outs8, dst=0, group=self.group)
         if self.rank != 0:
+            self._record(t_start, t_bcast, t_comp, self._stamp(), b_local)
             return None
         parts: List[np.ndarray] = []
         for r in range(self.world):
             a, bnd = shard_bounds(B, self.world, r)
             parts.append(outs8[r].view(torch.int16)[: bnd - a].cpu().numpy())
+        self._record(t_start, t_bcast, t_comp, self._stamp(), b_local)
         return np.concatenate(parts, 0)
+
+    def _stamp(self):
+        if not self.timing:
+            return 0.0
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        return time.perf_counter()
+
+    def _record(self, t0, t1, t2, t3, b_local):
+        if self.timing:
+            self.last_timing = {"bcast_ms": 1e3 * (t1 - t0), "compute_ms": 1e3 * (t2 - t1), "gather_ms": 1e3 * (t3 - t2), "b_local": b_local}
+
+    def timing_summary(self):
+        """Every rank calls it after a timed pass: rank 0 gets {"per_rank_ms": {"min", "max", "all"}, "bcast_ms", "gather_ms"} of the
+        LAST pass -- per-rank compute time (the straggler is max - min), the broadcast as the slowest rank saw it, the gather as rank 0
+        saw it -- the other ranks None."""
+        t = self.last_timing or {"bcast_ms": 0.0, "compute_ms": 0.0, "gather_ms": 0.0}
+        mine = torch.tensor([t["compute_ms"], t["bcast_ms"], t["gather_ms"]], dtype=torch.float64, device=self.device)
+        if self.collective:
+            alls = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(alls, mine, group=self.group)
+        else:
+            alls = [mine]
+        if self.rank != 0:
+            return None
+        rows = [a.cpu().tolist() for a in alls]
+        comp = [r[0] for r in rows]
+        return {"per_rank_ms": {"min": min(comp), "max": max(comp), "all": [round(c, 3) for c in comp]},
+                "bcast_ms": max(r[1] for r in rows), "gather_ms": rows[0][2]}
 
 
 def generate_for_batch_dp(prompts: Optional[Sequence[str]], encode: Callable, compute: Callable, n_samples: int, device,
-                          guidance: float = 3, samples: int = 1, batch_size: int = 8, group=None):
+                          guidance: float = 3, samples: int = 1, batch_size: int = 8, group=None, timings: Optional[dict] = None):
     """Prompt-level data-parallel `generate_for_batch` (tango.py:51-64 is the loop this shards).
 
     Every rank calls it; only rank 0's `prompts` are read (other ranks may pass None).  Per pass rank 0 runs the text
@@ -127,7 +169,9 @@ def generate_for_batch_dp(prompts: Optional[Sequence[str]], encode: Callable, co
     serial stage SURVEY.md 8e names), the embeddings are broadcast, each rank generates its contiguous shard
     (`compute(embeds_local, mask_local, sample_offset, seed) -> int16 [b_local, n_samples]`) and rank 0 gathers.
     Returns on rank 0 what `Tango.generate_for_batch` returns (list of waveforms, grouped per prompt when samples > 1);
-    None on the other ranks."""
+    None on the other ranks.  `timings` (a dict, optional): rank 0 appends the host wall time of every `encode` call to
+    `timings["encode_ms"]` and of every pass to `timings["pass_ms"]` -- the text encoder is the only serial stage, and pass k+1's
+    encode is issued while pass k's denoise runs, so encode_ms << pass_ms is the measurement that it is hidden."""
     dp = DataParallelGenerator(compute, torch.device(device), group)
     n = torch.tensor([len(prompts) if dp.rank == 0 else 0], dtype=torch.int64, device=dp.device)
     if dp.collective:
@@ -141,14 +185,20 @@ def generate_for_batch_dp(prompts: Optional[Sequence[str]], encode: Callable, co
 
     def encode_pass(k):
         if dp.rank == 0 and k < n:
+            t0 = time.perf_counter()
             nxt[k] = encode(list(prompts[k:k + per_pass]), samples, guidance)
+            if timings is not None:
+                timings.setdefault("encode_ms", []).append(1e3 * (time.perf_counter() - t0))
 
     encode_pass(0)
     for k in range(0, n, per_pass):
         pe, pm = nxt.pop(k) if dp.rank == 0 else (None, None)
+        t0 = time.perf_counter()
         wav = dp.generate(pe, pm, guidance, n_samples, after_compute=lambda k=k: encode_pass(k + per_pass))
         if dp.rank == 0:
             outputs += [w for w in wav]
+            if timings is not None:
+                timings.setdefault("pass_ms", []).append(1e3 * (time.perf_counter() - t0))
     if dp.rank != 0:
         return None
     if samples == 1:

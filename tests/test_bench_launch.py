@@ -26,6 +26,9 @@ def test_bench_self_launches_for_gpus_2():
     out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "0", "--batch", "3"])
     assert out["stub"] is True and out["n_gpus"] == 2 and out["ranks"] == 2 and out["steps"] == 2
     assert out["config"]["global_batch"] == 6          # weak scaling: 3 prompts per rank
+    # the line shows a straggler rank or a slow collective, not one number
+    pr = out["per_rank_ms"]
+    assert len(pr["all"]) == 2 and 0.0 <= pr["min"] <= pr["max"] and out["bcast_ms"] >= 0.0 and out["gather_ms"] >= 0.0
 
 
 def test_bench_single_process_default():

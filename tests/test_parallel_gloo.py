@@ -108,12 +108,15 @@ def _worker_prompts(rank, world, port, samples, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.manual_seed(100 + rank)   # per-rank generators differ: the batch seed must still come from rank 0 only
+        timings = {}
         out = generate_for_batch_dp(PROMPTS if rank == 0 else None, _fake_encode, _fake_compute_prompt, N_SAMPLES, "cpu",
-                                    guidance=3.0, samples=samples, batch_size=2)
+                                    guidance=3.0, samples=samples, batch_size=2, timings=timings)
         if rank == 0:
+            # the serial stage is timed per pass on rank 0 (5 prompts, 2 per rank and pass -> 2 passes); other ranks record nothing
+            assert len(timings["encode_ms"]) == 2 and len(timings["pass_ms"]) == 2 and min(timings["encode_ms"]) >= 0.0
             q.put(out)
         else:
-            assert out is None
+            assert out is None and timings == {}
     finally:
         dist.destroy_process_group()
 

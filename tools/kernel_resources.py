@@ -42,6 +42,33 @@ def kernel_resources(lib):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def template_args(mangled):
+    """('kernel_name', [template arguments]) of an Itanium-mangled `tango::name<...>(...)` kernel symbol -- only the argument kinds
+    this library's kernels use: types f / DF16_ / DF16b -> 'f32' / 'f16' / 'bf16', Lb0E / Lb1E -> bool, Li<n>E / Lin<n>E -> int.
+    (binutils' c++filt does not know DF16_; llvm-cxxfilt is not in this image.)  Returns (name, None) for anything else."""
+    m = re.match(r"_ZN5tango(\d+)", mangled)
+    if not m:
+        return mangled, None
+    n = int(m.group(1))
+    start = m.end()
+    name, rest = mangled[start:start + n], mangled[start + n:]
+    if not rest.startswith("I"):
+        return name, []
+    rest, args = rest[1:], []
+    while rest and not rest.startswith("E"):
+        mm = re.match(r"DF16_|DF16b|f|Lb([01])E|Li(n?)(\d+)E", rest)
+        if not mm:
+            return name, None
+        tok = mm.group(0)
+        if tok == "DF16_": args.append("f16")
+        elif tok == "DF16b": args.append("bf16")
+        elif tok == "f": args.append("f32")
+        elif tok.startswith("Lb"): args.append(mm.group(1) == "1")
+        else: args.append(-int(mm.group(3)) if mm.group(2) else int(mm.group(3)))
+        rest = rest[len(tok):]
+    return name, args
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default=os.path.join(ROOT, "tango_amd", "lib", "libtango_hip.so"))
