@@ -446,6 +446,10 @@ def main():
             wl5 = Workload(args, device, True, "bf16", True)
             oc["config5_shard_xl_bf16_fp8attn_b8_200step"] = timed_single_gpu(wl5, args, 8, 200)
             del wl5
+            # row g1 (round 6): the same shard with P.V on the MX instruction (v_mfma_scale_f32_16x16x128_f8f6f4, 128 keys per MFMA)
+            wl5x = Workload(args, device, True, "bf16", 2)
+            oc["config5_shard_xl_bf16_mxfp8attn_b8_200step"] = timed_single_gpu(wl5x, args, 8, 200)
+            del wl5x
             # the reference's own arithmetic (fp32) at config 3's batch, a REAL 200-step pass (20-step warm-up builds the plans), priced
             # against the 157.3-TFLOP/s f32 MFMA peak -- the like-for-like record next to the fp16 headline
             wl32 = Workload(args, device, False, "fp32", False)

@@ -108,7 +108,9 @@ typedef struct tango_config {
   int32_t unet_music;
   /* BASELINE config 5 ("bf16 + fp8 MFMA attention"): != 0 runs the P.V product of the UNet's self-attention sites on
    * v_mfma_f32_16x16x32_fp8_fp8 (P and V as OCP e4m3, fp32 accumulation, fp32 softmax statistics; Q.K^T stays in `dtype`).
-   * 16-bit engines only.  Measured deviation: DESIGN.md section 3. */
+   * 16-bit engines only.  Measured deviation: DESIGN.md section 3.  2 = the same product on the MX instruction
+   * v_mfma_scale_f32_16x16x128_f8f6f4 (128 keys per MFMA, unit block scales, twice the matrix-pipe rate) at the sites whose sequence
+   * length is a multiple of 128; same roundings. */
   int32_t unet_attn_fp8;
 } tango_config_t;
 
@@ -253,7 +255,8 @@ int tango_op_layernorm(int dtype, const float* x, const float* gamma, const floa
                        void* stream);
 int tango_op_attention(int dtype, const float* q, const float* k, const float* v, const float* bias, float* out, int B, int heads,
                        int Sq, int Skv, float scale, void* stream);
-/* as tango_op_attention; flags bit 0: P.V on the fp8 MFMA (16-bit dtypes, no bias, Skv % 64 == 0) */
+/* as tango_op_attention; flags bit 0: P.V on the fp8 MFMA (16-bit dtypes, no bias, Skv % 64 == 0); bit 1 (with bit 0): on the MX
+ * instruction, 128 keys per MFMA (Skv % 128 == 0) */
 int tango_op_attention_ex(int dtype, const float* q, const float* k, const float* v, const float* bias, float* out, int B, int heads,
                           int Sq, int Skv, float scale, int flags, void* stream);
 /* fused cross-attention block of BasicTransformerBlock (diffusers attention.py:312-323: attn2(norm2(x), text, mask) + x) as the engine

@@ -82,14 +82,22 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // row 0 is all ones (no LDS: it is a register constant), instead of 32 v_add_f32 per tile and wave in a loop that is VALU-bound
 // (profiles/r4_attention_loop_isa_count.txt: 182 VALU-class instructions per 32 MFMAs).  The sum is then taken of the ROUNDED P the
 // P.V MFMAs consume (fp32 accumulation), i.e. numerator and denominator see the same weights.
-template <typename T, int QB, bool MASKED, int NW, int MINW, bool PB = false, bool F8 = false, bool MSUM = false>
+// X8 (round 6; row g1 of the scope table, BASELINE config 5): P.V on the MX instruction v_mfma_scale_f32_16x16x128_f8f6f4 with unit
+// block scales -- 128 KEYS per MFMA (the contraction of P.V runs over keys, so the 64-wide heads do not limit it; Q.K^T contracts over
+// head_dim = 64 and stays on the 16-bit MFMA), twice the matrix-pipe rate of the non-scaled fp8 MFMA.  The tile is 128 keys; a lane's
+// B operand is the 32 P^T values it already holds ([key block kb = 0..7][r = 0..3] -> byte 4 kb + r), the A operand 32 e4m3 bytes of
+// one V^T row staged in that key order (two ds_read_b128).  Same roundings as F8 (e4m3 P carried as 2^8 P, e4m3 V, fp32 accumulation,
+// row sums of the rounded P on the matrix pipe): only the summation order inside the MFMA differs.
+template <typename T, int QB, bool MASKED, int NW, int MINW, bool PB = false, bool F8 = false, bool MSUM = false, bool X8 = false>
 __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p) {
+  static_assert(!X8 || (F8 && MSUM && !MASKED), "MX P.V: the unmasked fp8 variant with matrix-pipe row sums");
   static_assert(!MSUM || sizeof(T) == 2, "matrix-pipe row sums: the P^T fragments of the 16-bit engines only");
   static_assert(!PB || MASKED, "position bias rides on the masked path");
   static_assert(!F8 || (sizeof(T) == 2 && !PB), "fp8 P.V: 16-bit engines, no position bias");
   constexpr int NTH = NW * 64;
   constexpr int EPV = 16 / (int)sizeof(T);
-  constexpr int D = 64, KVT = 64;
+  constexpr int D = 64, KVT = X8 ? 128 : 64;
+  constexpr int NKB = KVT / 16;                     // 16-key blocks per tile
   constexpr bool HALF = sizeof(T) == 2;
   constexpr int ROWB = D * (int)sizeof(T);          // bytes per K row == bytes per V^T row (64 kv)
   constexpr int LDSR = HALF ? ROWB : ROWB + 16;     // 128-byte rows are XOR-swizzled, 256-byte rows padded
@@ -97,7 +105,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
   constexpr int PPR = ROWB / 16;
   constexpr int NPIECE = KVT * PPR;
   constexpr int NPASS = (NPIECE + NTH - 1) / NTH;
-  constexpr int STAGE = 2 * KVT * LDSR;
+  constexpr int VPPR = X8 ? 16 : PPR;               // 16-byte pieces per staged V^T row (X8: 128 keys of a 16-bit row)
+  constexpr int STAGE = X8 ? KVT * LDSR + D * 128 : 2 * KVT * LDSR;
   constexpr float LOG2E = 1.4426950408889634f;
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
@@ -144,20 +153,24 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
   // Addresses are a wave-uniform tile base (advanced per tile on the scalar unit) plus a per-thread 32-bit offset that
   // is constant over the loop: no 64-bit VALU address arithmetic per tile (round 1: ~60 VALU of the ~250 per tile in a
   // VALU-co-limited loop).  MASKED == false means Skv % 64 == 0 and ldvt >= Skv: every piece is in range, no tests.
-  u32x4 kreg[NPASS], vreg[NPASS];
+  // X8: the 128-key tile is staged in two parts (its first half travels under Q.K^T, the second under the softmax and P.V): 16 staging
+  // registers live at a time instead of 32 (the 16-row form spilled 19 VGPRs at three waves per SIMD otherwise)
+  constexpr int NSTG = X8 ? NPASS / 2 : NPASS;
+  u32x4 kreg[NSTG], vreg[NSTG];
   unsigned koff[NPASS], voff[NPASS];
 #pragma unroll
   for (int i = 0; i < NPASS; ++i) {
     const int id = tid + i * NTH;
     const int row = id / PPR, pc = id % PPR;
     koff[i] = (unsigned)row * (unsigned)(p.ldk * (int64_t)sizeof(T)) + pc * 16;
-    voff[i] = (unsigned)row * (unsigned)(p.ldvt * (int64_t)sizeof(T)) + pc * 16;
+    voff[i] = X8 ? (unsigned)(id / VPPR) * (unsigned)(p.ldvt * (int64_t)sizeof(T)) + (id % VPPR) * 16
+                 : (unsigned)row * (unsigned)(p.ldvt * (int64_t)sizeof(T)) + pc * 16;
   }
   auto load_tile = [&](int kv0) {
     const unsigned char* Kt = (const unsigned char*)Kp + (int64_t)kv0 * p.ldk * (int64_t)sizeof(T);
     const unsigned char* Vt = (const unsigned char*)Vp + (int64_t)kv0 * (int64_t)sizeof(T);
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
+    for (int i = 0; i < NSTG; ++i) {
       const int id = tid + i * NTH;
       const int row = id / PPR, pc = id % PPR;
       if (NPIECE % NTH != 0 && id >= NPIECE) continue;
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
     unsigned char* Ks = smem + st * STAGE;
     unsigned char* Vs = Ks + KVT * LDSR;
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
+    for (int i = 0; i < NSTG; ++i) {
       const int id = tid + i * NTH;
       const int row = id / PPR, pc = id % PPR;
       if (NPIECE % NTH != 0 && id >= NPIECE) continue;
@@ -211,26 +224,69 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
     }
   };
 
+  // X8 staging, two parts of NSTG passes each (separate lambdas: sharing load_tile / store_tile changed the register allocation of
+  // every other instantiation of this template)
+  auto load_part = [&](int kv0, const int part) {
+    const unsigned char* Kt = (const unsigned char*)Kp + (int64_t)kv0 * p.ldk * (int64_t)sizeof(T);
+    const unsigned char* Vt = (const unsigned char*)Vp + (int64_t)kv0 * (int64_t)sizeof(T);
+#pragma unroll
+    for (int j = 0; j < NSTG; ++j) {
+      kreg[j] = *(const u32x4*)(Kt + koff[part * NSTG + j]);
+      vreg[j] = *(const u32x4*)(Vt + voff[part * NSTG + j]);
+    }
+  };
+  auto store_part = [&](int st, const int part) {
+    unsigned char* Ks = smem + st * STAGE;
+#pragma unroll
+    for (int j = 0; j < NSTG; ++j) {
+      const int i = part * NSTG + j;
+      const int id = tid + i * NTH;
+      const int row = id / PPR, pc = id % PPR;
+        *(u32x4*)(Ks + row * LDSR + ((pc ^ (row & 7)) * 16)) = kreg[j];
+        // V^T as e4m3, 128-byte rows of eight 16-byte slots: lane group gg of the MX MFMA reads bytes [32 gg, 32 gg + 32) = slots 2 gg,
+        // 2 gg + 1, byte 4 kb + r of them = key 16 kb + 4 gg + r.  Piece vpc of V^T row vrow holds keys 8 vpc .. 8 vpc + 7: kb = vpc >> 1,
+        // gg = 2 (vpc & 1) + (e >> 2).  slot ^= A(row) with A = {0,1,4,5,6,7,2,3}[(row >> 1) & 7]: the 16 lanes of every ds_read_b128
+        // lane group (MI355X_MICROARCH.md) then touch 16 distinct 16-byte slots of the 256-byte bank row
+        const int vrow = id / VPPR, vpc = id % VPPR;
+        T e[8];
+        __builtin_memcpy(e, &vreg[j], 16);
+        float f[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) f[u] = __builtin_amdgcn_fmed3f(to_f(e[u]), -448.f, 448.f);
+        const int kb = vpc >> 1, gg0 = 2 * (vpc & 1);
+        const int ar = (vrow >> 1) & 7, sw = ar < 2 ? ar : (ar < 6 ? ar + 2 : ar - 4);
+        unsigned char* vr = Ks + KVT * LDSR + vrow * 128 + 4 * (kb & 3);
+        *(unsigned*)(vr + (((2 * gg0 + (kb >> 2)) ^ sw) * 16)) = pack_fp8x4(f[0], f[1], f[2], f[3]);
+        *(unsigned*)(vr + (((2 * gg0 + 2 + (kb >> 2)) ^ sw) * 16)) = pack_fp8x4(f[4], f[5], f[6], f[7]);
+    }
+  };
+
   const int ntile = (p.Skv + KVT - 1) / KVT;
-  load_tile(0);
-  store_tile(0);
+  if constexpr (X8) {
+    load_part(0, 0); store_part(0, 0);
+    load_part(0, 1); store_part(0, 1);
+  } else {
+    load_tile(0);
+    store_tile(0);
+  }
   __syncthreads();
 
   for (int t = 0; t < ntile; ++t) {
     const int kv0 = t * KVT;
     const bool more = t + 1 < ntile;
-    if (more) load_tile(kv0 + KVT);
+    if constexpr (X8) { if (more) load_part(kv0 + KVT, 0); }
+    else { if (more) load_tile(kv0 + KVT); }
     const unsigned char* Ks = smem + (t & 1) * STAGE;
     const unsigned char* Vs = Ks + KVT * LDSR;
 
     // ---- S^T = K Q^T ----
-    f32x4 sacc[QB][4];
+    f32x4 sacc[QB][NKB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) sacc[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int kb = 0; kb < NKB; ++kb) sacc[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
+    for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
       for (int ks = 0; ks < NKG; ++ks) {
         const int off = HALF ? (((ks * 4 + g) ^ (lane & 7)) * 16) : ks * 64 + g * 16;
@@ -239,6 +295,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
         for (int qb = 0; qb < QB; ++qb) AMma<T>::run(sacc[qb][kb], kf, qf[qb][ks]);
       }
     }
+
+    if constexpr (X8) { if (more) { store_part((t + 1) & 1, 0); load_part(kv0 + KVT, 1); } }
 
     // ---- online softmax in the exp2 domain (per lane: one q column, 16 kv values per q block) ----
     // MASKED == false: self-attention with Skv a multiple of 64 (no bias, no tail) -> no per-key offsets at all
@@ -274,7 +332,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
         // unmasked: max(sc2 * s) == sc2 * max(s) (sc2 > 0), so the scale is applied once to the maximum and otherwise
         // rides along in the exponent's FMA
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) mt = fmaxf(mt, sacc[qb][kb][r]);
         mnew = fmaxf(mrow[qb], quad_max(mt) * sc2);
@@ -292,7 +350,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
       float rs = 0.f;
       const float moff = F8 ? mnew - 8.f : mnew;         // F8: P is carried as 2^8 P (<= 256 < 448 = e4m3 max); cancels in O / l
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
+      for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float pv = MASKED ? __builtin_amdgcn_exp2f(sacc[qb][kb][r] - moff)
@@ -304,7 +362,30 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
     }
 
     // ---- O^T += V^T P^T ----
-    if constexpr (F8) {
+    if constexpr (X8) {
+      typedef int i32x8 __attribute__((ext_vector_type(8)));
+      constexpr int UNIT = 0x7F7F7F7F;                   // E8M0 block scales 2^0 for both operands
+      i32x8 pf8[QB];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) pf8[qb][kb] = (int)pack_fp8x4(sacc[qb][kb][0], sacc[qb][kb][1], sacc[qb][kb][2], sacc[qb][kb][3]);
+      const int ar = (l15 >> 1) & 7, sw = ar < 2 ? ar : (ar < 6 ? ar + 2 : ar - 4);     // (row >> 1) & 7 with row = 16 db + l15
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const unsigned char* vr = Vs + (db * 16 + l15) * 128;
+        const u32x4 v0 = *(const u32x4*)(vr + (((2 * g) ^ sw) * 16)), v1 = *(const u32x4*)(vr + (((2 * g + 1) ^ sw) * 16));
+        const i32x8 vf8 = i32x8{(int)v0[0], (int)v0[1], (int)v0[2], (int)v0[3], (int)v1[0], (int)v1[1], (int)v1[2], (int)v1[3]};
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+          oacc[qb][db] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(vf8, pf8[qb], oacc[qb][db], 0, 0, 0, UNIT, 0, UNIT);
+      }
+      const int o8 = (int)ones[0];
+      const i32x8 ones8 = i32x8{o8, o8, o8, o8, o8, o8, o8, o8};
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+        lacc[qb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones8, pf8[qb], lacc[qb], 0, 0, 0, UNIT, 0, UNIT);
+    } else if constexpr (F8) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         long pf8[QB];
@@ -366,7 +447,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
         }
       }
     }
-    if (more) store_tile((t + 1) & 1);
+    if constexpr (X8) { if (more) store_part((t + 1) & 1, 1); }
+    else { if (more) store_tile((t + 1) & 1); }
     __syncthreads();
   }
 
@@ -420,6 +502,23 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
   if (p.fp8_pv && sizeof(T) != 2) TANGO_FAIL("attention: fp8 P.V needs a 16-bit engine (Q.K^T stays in the engine dtype)");
   //  never fall back silently: a config-5 run must not measure the 16-bit kernel under the fp8 label
   if (p.fp8_pv && (masked || p.pos_bias)) TANGO_FAIL("attention: fp8 P.V is implemented for unmasked sites with Skv % 64 == 0 only");
+  if (p.fp8_pv == 2 && p.Skv % 128 != 0) TANGO_FAIL("attention: MX fp8 P.V (128 keys per MFMA) needs Skv % 128 == 0");
+  if constexpr (sizeof(T) == 2) {
+    if (p.fp8_pv == 2) {
+      // MX P.V (X8): 128-key tiles.  Two forms, picked by TANGO_ATTN_X8_QB (measured: DESIGN.md section 5, round 6): 32 query rows per
+      // wave at two waves per SIMD (the 64 S^T accumulators of a 128-key tile do not fit three), or 16 rows per wave at three
+      const bool qb2 = tuning().attn_x8_qb == 2 && p.Sq % 128 == 0;
+      if (qb2) {
+        dim3 grid((unsigned)(p.Sq / 128), (unsigned)p.heads, (unsigned)p.B);
+        hipLaunchKernelGGL((attn_kernel<T, 2, false, 4, 2, false, true, true, true>), grid, dim3(256), 0, s, p);
+      } else {
+        dim3 grid((unsigned)((p.Sq + 63) / 64), (unsigned)p.heads, (unsigned)p.B);
+        hipLaunchKernelGGL((attn_kernel<T, 1, false, 4, 3, false, true, true, true>), grid, dim3(256), 0, s, p);
+      }
+      TANGO_HIP(hipGetLastError());
+      return 0;
+    }
+  }
   if (p.pos_bias) {   // text-encoder self-attention (short sequences): one query block per wave
     dim3 grid((unsigned)((p.Sq + 63) / 64), (unsigned)p.heads, (unsigned)p.B);
     hipLaunchKernelGGL((attn_kernel<T, 1, true, 4, 3, true>), grid, dim3(256), 0, s, p);

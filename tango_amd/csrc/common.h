@@ -283,7 +283,7 @@ struct AttnParams {
   const float* pos_bias = nullptr; // [heads][Sq][Skv] additive, shared by the batch (T5 relative position bias) or null
   int B, heads, Sq, Skv;
   float scale;
-  int fp8_pv = 0;                 // 16-bit engines, unmasked (self-attention) sites: P and V as e4m3 on the fp8 MFMA (attention.hip)
+  int fp8_pv = 0;                 // 16-bit engines, unmasked (self-attention) sites: P and V as e4m3 on the fp8 MFMA (attention.hip); 2 = the MX instruction (128 keys per MFMA, unit scales)
 };
 int launch_attention(int dtype, const AttnParams& p, hipStream_t s);
 

@@ -206,9 +206,9 @@ struct Builder {
   }
 
   void attention(const TView& q, const TView& k, const void* vt, int64_t ldvt, const TView& o, const float* bias, int B, int heads,
-                 int Sq, int Skv, float scale = 0.125f, const float* pos_bias = nullptr, bool fp8_pv = false) {
+                 int Sq, int Skv, float scale = 0.125f, const float* pos_bias = nullptr, int fp8_pv = 0) {
     AttnParams p;
-    p.fp8_pv = fp8_pv ? 1 : 0;
+    p.fp8_pv = fp8_pv;                // 0: engine dtype, 1: non-scaled fp8 MFMA, 2: MX fp8 (128 keys per MFMA)
     p.q = q.p; p.ldq = q.ld; p.k = k.p; p.ldk = k.ld; p.vt = vt; p.ldvt = ldvt; p.o = o.p; p.ldo = o.ld;
     p.bias = bias; p.pos_bias = pos_bias; p.B = B; p.heads = heads; p.Sq = Sq; p.Skv = Skv; p.scale = scale;
     const int d = dt;
@@ -307,8 +307,9 @@ struct Builder {
     TView a = alloc(rows_p, C);
     // self-attention; `unet_attn_fp8` (BASELINE config 5): P.V on the fp8 MFMA at the sites that dominate the attention time
     // (unmasked, Skv a multiple of 64); cross-attention (64 text tokens, masked) stays in the engine dtype
+    // (unet_attn_fp8 == 2, round 6: the MX instruction, 128 keys per MFMA, where the sequence is a multiple of 128)
     attention(slice(qkv, 0, C, esz), slice(qkv, C, C, esz), vt, HW, a, nullptr, Bp, w.heads, HW, HW, 0.125f, nullptr,
-              E.cfg.unet_attn_fp8 != 0 && dt != DT_F32 && HW % 64 == 0);
+              (E.cfg.unet_attn_fp8 != 0 && dt != DT_F32 && HW % 64 == 0) ? ((E.cfg.unet_attn_fp8 == 2 && HW % 128 == 0) ? 2 : 1) : 0);
     TView h1 = alloc(rows, C);
     TView h2 = h;                       // h is dead after h1 was produced
     const int Lp8 = (L + 7) / 8 * 8;

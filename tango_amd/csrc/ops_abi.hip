@@ -421,6 +421,10 @@ int tango_op_attention_ex(int dt, const float* q, const float* k, const float* v
   if (flags & 1) {
     if (bias || Skv % 64 != 0) TANGO_FAIL("op_attention_ex: the fp8 P.V path takes unmasked problems with Skv % 64 == 0");
     p.fp8_pv = 1;
+    if (flags & 2) {
+      if (Skv % 128 != 0) TANGO_FAIL("op_attention_ex: the MX fp8 P.V path takes Skv % 128 == 0");
+      p.fp8_pv = 2;
+    }
   }
   TANGO_TRY(launch_attention(dt, p, s));
   TANGO_TRY(to_f32(dt, ot, C, out, (int64_t)B * Sq, C, s));

@@ -30,7 +30,7 @@ struct Tuning {
   bool no_gn_coop;          // TANGO_NO_GN_COOP=1       A/B: cooperative single-launch GroupNorm (norm.hip gn_coop_kernel) out (round 4)
   bool gn_coop_all;         // TANGO_GN_COOP_ALL=1      tests: that kernel for every geometry it can hold, not only where it was measured faster
   bool gn_coop_force_fb;    // TANGO_GN_COOP_FORCE_FALLBACK=1 tests: every workgroup of that kernel takes the no-rendezvous fallback (bit-identical results required) (round 5)
-  int graph_steps;          // TANGO_GRAPH_STEPS=k      denoise: k UNet steps per captured hipGraph (default 10 for UNet batches <= 16, else 1; 1 = one replay per step) (round 5)
+  int graph_steps;          // TANGO_GRAPH_STEPS=k      denoise: k UNet steps per captured hipGraph (default 1 = one replay per step: measured, no inter-replay gap to remove) (round 5)
   int unet_chains;          // TANGO_UNET_CHAINS=1|2    denoise: the UNet batch as one kernel sequence or as two independent halves in two branches of the captured graph (Engine::unet_chains_for; unset = the measured rule) (round 5)
   bool no_cfg_shared;       // TANGO_NO_CFG_SHARED=1    A/B: the CFG-shared prefix of a guidance step (conv_in ... first self-attention once for both halves) off (round 5)
   bool stream_spec;         // TANGO_STREAM_SPEC=0|1     lin_stream_kernel: compile-time GEGLU + folded-LayerNorm epilogue for the level-0 projection (default on) (round 5)
@@ -42,6 +42,7 @@ struct Tuning {
   int duo_min_tiles;        // TANGO_DUO_MIN_TILES=n    ... that have at least n tiles of 256 x 160
   int duo_mask;             // TANGO_DUO_MASK=bits      ... of these classes: 1 plain, 2 GEGLU, 4 folded LayerNorm (incl. transposed V), 8 folded LayerNorm + GEGLU
   int duo_prio;             // TANGO_DUO_PRIO=0..1      0 = s_setprio 1 around its MFMAs, 1 = no priority changes
+  int attn_x8_qb;           // TANGO_ATTN_X8_QB=1|2     MX fp8 P.V attention (unet_attn_fp8 = 2): 16 query rows per wave at three waves per SIMD, or 32 at two (round 6)
   int conv_tall;            // TANGO_CONV_TALL=0|1      3x3 wide conv on the 512-pixel x 160-channel form of the tile where the halo fits (round 6: half the weight DMA per MFMA)
   int wide_pipe;            // TANGO_WIDE_PIPE=0|1      256 x 320 GEMM / conv: in-wave software pipeline (fragments of item i+1 requested under the MFMAs of item i) instead of the ping-pong read / multiply parts (round 6)
 };
@@ -81,6 +82,7 @@ inline Tuning read_tuning() {
   x.duo_prio = num("TANGO_DUO_PRIO", 0);
   x.wide_pipe = num("TANGO_WIDE_PIPE", 0);
   x.conv_tall = num("TANGO_CONV_TALL", 0);
+  x.attn_x8_qb = num("TANGO_ATTN_X8_QB", 2);
   const char* wp = getenv("TANGO_WIDE_PRIO");
   x.wide_prio = (wp && wp[0] >= '0' && wp[0] <= '2') ? wp[0] - '0' : 0;
   return x;

@@ -78,7 +78,7 @@ class Engine:
         self.t5_cfg = dict(t5) if t5 is not None else None
         self.vae_encoder = bool(vae_encoder) and vae is not None
         self.stft_cfg = dict(stft) if stft is not None else None
-        self.attn_fp8 = bool(attn_fp8)
+        self.attn_fp8 = int(attn_fp8)      # False / True, or 2: the MX instruction (128 keys per MFMA) where the sequence allows
         if self.attn_fp8 and dtype in ("fp32", "float32", "f32"):
             raise ValueError("attn_fp8 (P.V on the fp8 MFMA) needs a 16-bit engine dtype")
         c = _lib.TangoConfig()
@@ -93,7 +93,7 @@ class Engine:
                 c.unet_heads[i] = u["attention_head_dim"][i]
                 c.unet_cross_attn[i] = 1 if u["down_block_types"][i].startswith("CrossAttnDownBlock2D") else 0
             c.unet_music = 1 if u.get("music") else 0
-            c.unet_attn_fp8 = 1 if attn_fp8 else 0
+            c.unet_attn_fp8 = int(attn_fp8)
             c.unet_layers_per_block = u["layers_per_block"]
             c.unet_in_channels = u["in_channels"]
             c.unet_out_channels = u["out_channels"]

@@ -25,28 +25,47 @@ def f8(t):
     return t.to(torch.float8_e4m3fn).float()
 
 
-def emulate(qh, kh, vh, scale):
-    """[B, h, S, 64] tensors (already rounded to the engine dtype) -> O as the F8 kernel computes it"""
+def emulate(qh, kh, vh, scale, tile=64):
+    """[B, h, S, 64] tensors (already rounded to the engine dtype) -> O as the F8 kernel computes it (`tile` keys per online-softmax
+    step: 64 for the non-scaled fp8 MFMA, 128 for the MX form, whose running maximum moves once per 128 keys)"""
     B, H, Sq, _ = qh.shape
     Skv = kh.shape[2]
     m = torch.full((B, H, Sq, 1), -1e30)
     l = torch.zeros(B, H, Sq, 1)
     o = torch.zeros(B, H, Sq, 64)
     vq = f8(vh.clamp(-448, 448))
-    for t0 in range(0, Skv, 64):
-        s = (qh @ kh[:, :, t0:t0 + 64].transpose(-1, -2)) * scale
+    for t0 in range(0, Skv, tile):
+        s = (qh @ kh[:, :, t0:t0 + tile].transpose(-1, -2)) * scale
         mn = torch.maximum(m, s.amax(-1, keepdim=True))
         alpha = torch.exp(m - mn)
         p = 256.0 * torch.exp(s - mn)
         l = l * alpha + f8(p).sum(-1, keepdim=True)
-        o = o * alpha + f8(p) @ vq[:, :, t0:t0 + 64]
+        o = o * alpha + f8(p) @ vq[:, :, t0:t0 + tile]
         m = mn
     return o / l
 
 
+# mode: flags of tango_op_attention_ex and the launch-time form -- 1 = non-scaled fp8 MFMA (64-key tiles); 3 = the MX instruction
+# v_mfma_scale_f32_16x16x128_f8f6f4, 128 keys per MFMA (round 6), as 32 query rows per wave at two waves per SIMD ("mx_qb2") or 16
+# rows at three ("mx_qb1")
+@pytest.mark.parametrize("mode", ["fp8", "mx_qb2", "mx_qb1"])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("B,heads,S,spread", [(2, 2, 256, 1.0), (1, 5, 4096, 1.0), (2, 3, 64, 1.0), (1, 2, 1024, 4.0), (1, 1, 4096, 0.05)])
-def test_attention_fp8_pv(lib, dtype, B, heads, S, spread):
+def test_attention_fp8_pv(lib, mode, dtype, B, heads, S, spread):
+    import os
+    flags, tile = (1, 64) if mode == "fp8" else (3, 128)
+    if S % tile:
+        pytest.skip("the MX form takes Skv % 128 == 0")
+    os.environ["TANGO_ATTN_X8_QB"] = "1" if mode == "mx_qb1" else "2"
+    lib.tango_tuning_reload()
+    try:
+        _fp8_case(lib, flags, tile, dtype, B, heads, S, spread)
+    finally:
+        del os.environ["TANGO_ATTN_X8_QB"]
+        lib.tango_tuning_reload()
+
+
+def _fp8_case(lib, flags, tile, dtype, B, heads, S, spread):
     """`spread` scales the logits: 4.0 = peaked rows (one or two keys carry the weight), 0.05 = flat rows -- 4096 weights of
     ~1/4096 each, the case the 2^8 pre-scale exists for (unscaled they would all sit below e4m3's subnormal step 2^-9)"""
     g = torch.Generator().manual_seed(S + heads)
@@ -64,11 +83,11 @@ def test_attention_fp8_pv(lib, dtype, B, heads, S, spread):
     attn = (qh @ kh.transpose(-1, -2) * 0.125).softmax(-1)
     exact = (attn @ vh.clamp(-448, 448)).transpose(1, 2).reshape(B, S, C_)
     exact_unclamped = (attn @ vh).transpose(1, 2).reshape(B, S, C_)
-    emu = emulate(qh, kh, vh, 0.125).transpose(1, 2).reshape(B, S, C_)
+    emu = emulate(qh, kh, vh, 0.125, tile).transpose(1, 2).reshape(B, S, C_)
     out = torch.empty(B, S, C_, device="cuda")
     p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
     qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
-    rc = lib.tango_op_attention_ex(DT[dtype], p(qd), p(kd), p(vd), None, p(out), B, heads, S, S, 0.125, 1, None)
+    rc = lib.tango_op_attention_ex(DT[dtype], p(qd), p(kd), p(vd), None, p(out), B, heads, S, S, 0.125, flags, None)
     assert rc == 0, lib.tango_last_error().decode()
     out = out.cpu()
     assert torch.isfinite(out).all()
@@ -84,8 +103,8 @@ def test_attention_fp8_pv(lib, dtype, B, heads, S, spread):
     assert col0 <= 8e-2, col0                                # same bound as against the exact result below
     e_exact = (out - exact).abs().max().item() / scale
     rms = ((out - exact).pow(2).mean().sqrt() / exact.pow(2).mean().sqrt()).item()
-    print("fp8 P.V attention %s B=%d h=%d S=%d spread %.2f: vs emulation %.3e, vs exact softmax(QK^T)V max %.3e / rms %.3e (of the output scale)"
-          % (dtype, B, heads, S, spread, e_emu, e_exact, rms))
+    print("fp8 P.V attention (flags %d) %s B=%d h=%d S=%d spread %.2f: vs emulation %.3e, vs exact softmax(QK^T)V max %.3e / rms %.3e (of the output scale)"
+          % (flags, dtype, B, heads, S, spread, e_emu, e_exact, rms))
     out_tol = 4e-3 if dtype == "fp16" else 1.2e-2           # the 16-bit output rounding on top of the emulated arithmetic
     assert e_emu <= out_tol, e_emu
     assert e_exact <= 8e-2 and rms <= 4e-2, (e_exact, rms)
@@ -99,7 +118,7 @@ def test_attention_fp8_pv(lib, dtype, B, heads, S, spread):
     ex2 = (attn @ va).transpose(1, 2).reshape(B, S, C_)
     vd2 = v_any.cuda()
     assert lib.tango_op_attention_ex(DT[dtype], p(qd), p(kd), p(vd2), None, p(out_dev := torch.empty(B, S, C_, device="cuda")), B, heads, S, S,
-                                     0.125, 1, None) == 0
+                                     0.125, flags, None) == 0
     e2 = (out_dev.cpu() - ex2).abs().max().item() / ex2.abs().max().item()
     print("   off-grid V: vs exact %.3e" % e2)
     assert e2 <= 8e-2
@@ -113,6 +132,8 @@ def test_fp8_pv_argument_errors(lib):
     assert b"16-bit" in lib.tango_last_error()
     bias = torch.zeros(1, 64, device="cuda")
     assert lib.tango_op_attention_ex(2, p(x), p(x), p(x), p(bias), p(out), 1, 1, 64, 64, 0.125, 1, None) != 0   # masked site
+    assert lib.tango_op_attention_ex(2, p(x), p(x), p(x), None, p(out), 1, 1, 64, 64, 0.125, 3, None) != 0      # MX form: Skv % 128
+    assert b"128" in lib.tango_last_error()
     from tango_amd.engine import UNET_CONFIG_LARGE, Engine
     with pytest.raises(ValueError):
         Engine(unet=UNET_CONFIG_LARGE, dtype="fp32", attn_fp8=True)
@@ -131,11 +152,14 @@ def test_unet_forward_with_fp8_attention_tiny(dtype, tol):
     with torch.no_grad():
         ref = O.unet_forward(sd, cfg, x, 500, enc, None, prefix="unet.")
     outs = {}
-    for f8on in (False, True):
+    for f8on in (False, True, 2):           # 2: the MX form where the sequence is a multiple of 128, the non-scaled one elsewhere
         e = Engine(unet=cfg, dtype=dtype, attn_fp8=f8on)
         e.load_synthetic(1234)
         outs[f8on] = e.unet_forward(x.cuda(), 500, enc.cuda(), None).cpu()
     e0 = ((outs[False] - ref).abs().max() / ref.abs().max()).item()
     e1 = ((outs[True] - ref).abs().max() / ref.abs().max()).item()
     print("tiny UNet %s: rel err vs oracle %.3e, with fp8 P.V attention %.3e" % (dtype, e0, e1))
+    e2 = ((outs[2] - ref).abs().max() / ref.abs().max()).item()
+    print("   with MX fp8 P.V attention (128 keys per MFMA) %.3e" % e2)
     assert e1 <= tol and not torch.equal(outs[False], outs[True])
+    assert e2 <= tol and not torch.equal(outs[False], outs[2])

@@ -49,5 +49,15 @@ elif kind == "conv":
     out = torch.empty(B, Co, H, W, device="cuda")
     for _ in range(reps):
         assert lib.tango_op_conv2d(1, p(x), p(w), p(b), p(out), B, Cc, H, W, Co, 1, 0, None) == 0
+elif kind == "attention":
+    # attention B heads S [reps [flags]]   self-attention site of the UNet (d = 64); flags: 0 engine dtype, 1 fp8 P.V, 3 MX fp8 P.V
+    B, heads, S = [int(v) for v in sys.argv[2:5]]
+    reps = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+    flags = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    dt = 2 if os.environ.get("BENCH_DTYPE", "fp16") == "bf16" else 1
+    q, k, v = (torch.randn(B, S, heads * 64, device="cuda") for _ in range(3))
+    out = torch.empty_like(q)
+    for _ in range(reps):
+        assert lib.tango_op_attention_ex(dt, p(q), p(k), p(v), None, p(out), B, heads, S, S, C.c_float(0.125), flags, None) == 0, lib.tango_last_error()
 torch.cuda.synchronize()
 print("done")
