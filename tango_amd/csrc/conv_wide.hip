@@ -296,9 +296,21 @@ template <int I, int N, typename F> __device__ __forceinline__ void cwp_for(F&& 
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); cwp_for<I + 1, N>(f); }
 }
 
-template <typename T, bool RES, bool SK>
+// LOCK: all eight waves in step, one barrier per item (gemm_wide.hip).  The halo piece of chunk cc + 1 goes into the OTHER halo buffer, whose
+// last readers were the refills for item (cc, 0) during item (cc - 1, 8): done at the barrier that ended it.
+// MODE 2, SKEW (TANGO_WIDE_PIPE=3): ONE barrier per item AND staggered halves -- every wave meets the others once per item, but the 4-wave
+// halves do so at different points of their item (half A behind column group 1, half B behind group 6), so waves w and w + 4, which
+// share a SIMD, run half an item apart: the end-of-item tail of one (last refills + lgkmcnt(0)) lies under the other's MFMAs, and nobody
+// pays a second barrier.  Order per wave and item: [groups 0..P] wait own DMAs of item i + 2, barrier #i, [this item's DMAs one per group
+// behind the barrier, groups P+1..9].  Barrier #i is passed only when every wave has finished item i - 1 completely (its end-of-item
+// lgkmcnt(0) covers the refill reads, i.e. all reads of item i's operands), so the DMAs of item i -- weights of item i + 4 into the stage
+// item i was read from, halo piece of the next chunk into the other halo buffer -- overwrite nothing that is still read; and a wave's
+// first read of item i + 3's operands (group 0 of item i + 2) lies behind barrier #(i + 1), in front of which every wave has waited for
+// its own pieces of them.
+template <typename T, bool RES, bool SK, int MODE = 0>
 __global__ __launch_bounds__(512) void conv3x3_wide_pipe_kernel(const GemmParams p, const unsigned char* zero_page, const int SR, const int nseg,
                                                                 const int abytes, const int prio) {
+  constexpr bool LOCK = MODE == 1, SKEW = MODE == 2;
   constexpr int BM = 256, BN = 320, CB = 64, NST = 4;
   constexpr int BK = CB / (int)sizeof(T);
   constexpr int WST = BN * CB;
@@ -435,7 +447,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_pipe_kernel(const GemmParams
   cwp_lds_read_b32(hoff0, aoff_addr);               // item 0 issues halo piece 0 of chunk cc0 + 1
   cwp_lds_wait_all(wf, xf, hoff0);
   __builtin_amdgcn_sched_barrier(0);
-  if (half) pp_barrier();                           // the stagger
+  if (MODE == 0 && half) pp_barrier();              // the stagger (SKEW: it establishes itself at the first barrier)
   if (prio == 2 && half) __builtin_amdgcn_s_setprio(1);
   unsigned w_off0 = w_off0_init;
   asm volatile("" : "+v"(w_off0));
@@ -471,7 +483,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_pipe_kernel(const GemmParams
       __builtin_amdgcn_sched_barrier(0);
     });
     if (item + 2 < NI) wait_n(prev_h + (item + 3 < NI ? my_w : 0));
-    pp_barrier();
+    if (!LOCK) pp_barrier();
     // ---- H1: column groups 5-9 and this item's DMAs ----
     unsigned xa[TM];
 #pragma unroll
@@ -501,17 +513,79 @@ __global__ __launch_bounds__(512) void conv3x3_wide_pipe_kernel(const GemmParams
     pp_barrier();
     return iss_h ? 1 : 0;
   };
-  {
+  // SKEW item: half A's barrier sits behind column group 1, half B's behind group 6.  ONE body with wave-uniform run-time tests on
+  // `half` (two specialised loop bodies behind an if / else made the allocator spill 100+ accumulator registers at the join)
+  auto do_item_skew = [&](auto more1_tag, const int item, const int tap, const int cc, const int prev_h, unsigned& hoff) __attribute__((always_inline)) -> int {
+    constexpr bool MORE1 = decltype(more1_tag)::value;
+    constexpr int PA = 1, PB = 6;
+    const bool more_c = cc + 1 < cc1;
+    const int tap1 = tap == 8 ? 0 : tap + 1;
+    const int buf1 = tap == 8 ? ((cc + 1) & 1) : (cc & 1);
+    const int toff1 = (tap1 / 3) * HW2 + (tap1 % 3);
+    unsigned wsrc = wbase + (unsigned)((item + 1) & (NST - 1)) * WST;
+    asm volatile("" : "+v"(wsrc));
+    const bool iss_h = more_c && tap < CW_NA && tap * 8 + wave < HALO_RG;
+    const bool iss_w = item + NST < NI;
+    const int st4 = item & (NST - 1);
+    int koff4;
+    {
+      int t4 = tap + NST, c4 = cc;
+      if (t4 >= 9) { t4 -= 9; c4 = cc + 1; }
+      koff4 = (t4 * p.Cin + c4 * BK) * (int)sizeof(T);
+    }
+    // DMA slot sl = 0: the halo piece, 1..WRGW: weight row groups 0..WRGW-1 -- one per column group behind the wave's barrier
+    auto dma_slot = [&](auto sl_tag) {
+      constexpr int sl = decltype(sl_tag)::value;
+      if constexpr (sl == 0) { if (iss_h) issue_a_off(tap, cc + 1, (cc + 1) & 1, hoff); }
+      else if constexpr (sl <= WRGW) { if (iss_w) issue_w_one(sl - 1, koff4, st4, w_off0); }
+    };
+    auto sync_point = [&]() {
+      if (item + 2 < NI) wait_n(prev_h + (item + 3 < NI ? my_w : 0));
+      pp_barrier();
+    };
+    cwp_for<0, 9>([&](auto a_tag) {
+      constexpr int a = decltype(a_tag)::value;
+#pragma unroll
+      for (int b = 0; b < TM; ++b) Mma<T>::run(acc[a][b], wf[a], xf[b]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (MORE1) cwp_lds_read<a * 16 * CB>(wf[a], wsrc);
+      if constexpr (a == PA) { if (!half) sync_point(); }
+      if constexpr (a == PB) { if (half) sync_point(); }
+      if constexpr (a > PA && a - PA - 1 <= WRGW) { if (!half) dma_slot(std::integral_constant<int, a - PA - 1>{}); }
+      if constexpr (a > PB) { if (half) dma_slot(std::integral_constant<int, a - PB - 1>{}); }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    unsigned xa[TM];
+#pragma unroll
+    for (int b = 0; b < TM; ++b) xa[b] = MORE1 ? xaddr(b, buf1, toff1) : 0u;
+    cwp_for<0, TM>([&](auto b_tag) {
+      constexpr int b = decltype(b_tag)::value;
+      Mma<T>::run(acc[9][b], wf[9], xf[b]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (MORE1) cwp_lds_read<0>(xf[b], xa[b]);
+      if constexpr (2 + b <= WRGW) { if (half) dma_slot(std::integral_constant<int, 2 + b>{}); }     // half B: groups 7, 8 took slots 0, 1
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (MORE1) {
+      cwp_lds_read<9 * 16 * CB>(wf[9], wsrc);
+      cwp_lds_read_b32(hoff, aoff_addr + (unsigned)(tap1 < CW_NA ? tap1 : 0) * 2048u);
+      cwp_lds_wait_all(wf, xf, hoff);
+    }
+    return iss_h ? 1 : 0;
+  };
+  auto run_items = [&](auto item_fn) __attribute__((always_inline)) {
     int tap = 0, cc = cc0, prev_h = 0;
     unsigned hoff = hoff0;
 #pragma unroll 1
     for (int item = 0; item + 1 < NI; ++item) {
-      prev_h = do_item(std::true_type{}, item, tap, cc, prev_h, hoff);
+      prev_h = item_fn(std::true_type{}, item, tap, cc, prev_h, hoff);
       if (tap == 8) { tap = 0; ++cc; } else ++tap;
     }
-    do_item(std::false_type{}, NI - 1, 8, cc1 - 1, prev_h, hoff);
-  }
-  if (!half) pp_barrier();
+    item_fn(std::false_type{}, NI - 1, 8, cc1 - 1, prev_h, hoff);
+  };
+  if constexpr (SKEW) run_items(do_item_skew);
+  else run_items(do_item);
+  if (MODE == 0 && !half) pp_barrier();
   if (prio == 2) __builtin_amdgcn_s_setprio(0);
   __syncthreads();   // every wave is past its last fragment read: the halo / weight LDS becomes the staging area
   unsigned char* const slice = dsm + wave * (WIDE_STAGE_BYTES + 1280);
@@ -610,7 +684,8 @@ static int launch_conv_wide_pipe(const GemmParams& p, const unsigned char* zero_
   int lds = 2 * abytes + 4 * 320 * 64 + (CW_NA + 1) * 512 * 4;
   const int epi_lds = 8 * (WIDE_STAGE_BYTES + 1280);
   if (lds < epi_lds) lds = epi_lds;
-  auto kfn = conv3x3_wide_pipe_kernel<T, RES, SK>;
+  const int mode = tuning().conv_pipe;
+  auto kfn = mode == 3 ? conv3x3_wide_pipe_kernel<T, RES, SK, 2> : mode == 2 ? conv3x3_wide_pipe_kernel<T, RES, SK, 1> : conv3x3_wide_pipe_kernel<T, RES, SK, 0>;
   TANGO_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(kfn), lds));
   const int tiles = (p.M / 256) * (p.N / 320);
   hipLaunchKernelGGL(kfn, dim3((unsigned)tiles, (unsigned)(p.splitk > 1 ? p.splitk : 1)), dim3(512), lds, s, p, zero_page, g.SR, g.nseg, abytes, tuning().wide_prio);
@@ -621,7 +696,7 @@ static int launch_conv_wide_pipe(const GemmParams& p, const unsigned char* zero_
 
 template <typename T, bool RES, bool SK = false>
 static int launch_conv_wide_cfg(const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {
-  if (tuning().wide_pipe) return launch_conv_wide_pipe<T, RES, SK>(p, zero_page, s);
+  if (tuning().conv_pipe && !(SK ? false : conv_wide_tall_ok(p))) return launch_conv_wide_pipe<T, RES, SK>(p, zero_page, s);   // (TANGO_CONV_TALL=1 selects the ping-pong kernel's 512 x 160 form)
   if constexpr (!SK) {
     if (conv_wide_tall_ok(p)) return launch_conv_wide_sch<T, RES, false, 1, true>(p, zero_page, s);
   }

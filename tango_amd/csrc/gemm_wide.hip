@@ -279,7 +279,12 @@ template <int I, int N, typename F> __device__ __forceinline__ void wp_for(F&& f
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); wp_for<I + 1, N>(f); }
 }
 
-template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool XS>
+// LOCK (TANGO_WIDE_PIPE=2): the same in-wave pipeline with all eight waves in step and ONE barrier per item -- no stagger, no mid-item
+// barrier.  Both waves of a SIMD are then in their MFMA streams at the same time (each one's DMA / ds_read issue slots are covered by the
+// partner's MFMAs) and meet once per 80 MFMAs.  Stage kc % 4 is read (refills for item kc) during item kc - 1 only, all of those reads have
+// returned at the barrier that ends item kc - 1 (end-of-item lgkmcnt(0)), so chunk kc + 4 may be DMA'd into it anywhere in item kc; chunk
+// kc + 2 is first read during item kc + 1 and every wave has waited for its own pieces of it in the middle of item kc.
+template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool XS, bool LOCK = false>
 __global__ __launch_bounds__(512) void gemm_wide_pipe_kernel(const GemmParams p, const int prio) {
   constexpr int BM = 256, BN = 320, CB = 64, NST = 4;
   constexpr int ROWS = BM + BN, STAGE = ROWS * CB;
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(512) void gemm_wide_pipe_kernel(const GemmParams p,
   wp_for<0, TM>([&](auto b) { wp_lds_read<b * 16 * CB>(xf[b], xrow); });
   wp_lds_wait_all(wf, xf);
   __builtin_amdgcn_sched_barrier(0);
-  if (half) pp_barrier();                               // the stagger
+  if (!LOCK && half) pp_barrier();                      // the stagger
   if (prio == 2 && half) __builtin_amdgcn_s_setprio(1);
   // one item; MORE1: chunk kc+1 exists (refill the fragments) -- compile-time, the last item is peeled
   auto item = [&](auto more1_tag, const int kc) __attribute__((always_inline)) {
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(512) void gemm_wide_pipe_kernel(const GemmParams p,
       __builtin_amdgcn_sched_barrier(0);
     });
     if (kc + 2 < nk) wait_inflight(kc + 3 < nk ? 1 : 0);
-    pp_barrier();
+    if (!LOCK) pp_barrier();
     // ---- H1: column groups 5-9, the DMAs of chunk kc+4 ----
     wp_for<5, 9>([&](auto a_tag) {
       constexpr int a = decltype(a_tag)::value;
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(512) void gemm_wide_pipe_kernel(const GemmParams p,
   };
   for (int kc = 0; kc + 1 < nk; ++kc) item(std::true_type{}, kc);
   item(std::false_type{}, nk - 1);
-  if (!half) pp_barrier();
+  if (!LOCK && !half) pp_barrier();
   if (prio == 2) __builtin_amdgcn_s_setprio(0);
   __syncthreads();   // every wave is past its last fragment read: the operand stages become the staging area
   float mean[TM] = {0.f, 0.f, 0.f, 0.f}, rstd[TM] = {1.f, 1.f, 1.f, 1.f};
@@ -738,7 +743,7 @@ static int launch_wide_t(const GemmParams& p, hipStream_t s) {
 template <typename T, bool GEGLU, bool RES, bool LN, bool VT, bool XS>
 static int launch_wide_pipe_cfg(const GemmParams& p, hipStream_t s) {
   constexpr int LDS = 4 * (256 + 320) * 64;
-  auto kfn = gemm_wide_pipe_kernel<T, GEGLU, RES, LN, VT, XS>;
+  auto kfn = tuning().wide_pipe == 2 ? gemm_wide_pipe_kernel<T, GEGLU, RES, LN, VT, XS, true> : gemm_wide_pipe_kernel<T, GEGLU, RES, LN, VT, XS, false>;
   TANGO_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(kfn), LDS));
   const unsigned grid = (unsigned)((p.M / 256) * (p.N / 320));
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS, s, p, tuning().wide_prio);
@@ -762,7 +767,7 @@ static int launch_wide_pipe_t(const GemmParams& p, hipStream_t s, bool& taken) {
 }
 
 int launch_gemm_wide(int dtype, const GemmParams& p, hipStream_t s) {
-  if (tuning().wide_pipe && p.splitk <= 1 && p.K * 2 >= 4 * 64) {
+  if ((tuning().wide_pipe == 1 || tuning().wide_pipe == 2) && p.splitk <= 1 && p.K * 2 >= 4 * 64) {
     bool taken = false;
     int rc = 0;
     if (dtype == DT_F16) rc = launch_wide_pipe_t<f16>(p, s, taken);

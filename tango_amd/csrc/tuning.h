@@ -44,7 +44,8 @@ struct Tuning {
   int duo_prio;             // TANGO_DUO_PRIO=0..1      0 = s_setprio 1 around its MFMAs, 1 = no priority changes
   int attn_x8_qb;           // TANGO_ATTN_X8_QB=1|2     MX fp8 P.V attention (unet_attn_fp8 = 2): 16 query rows per wave at three waves per SIMD, or 32 at two (round 6)
   int conv_tall;            // TANGO_CONV_TALL=0|1      3x3 wide conv on the 512-pixel x 160-channel form of the tile where the halo fits (round 6: half the weight DMA per MFMA)
-  int wide_pipe;            // TANGO_WIDE_PIPE=0|1      256 x 320 GEMM / conv: in-wave software pipeline (fragments of item i+1 requested under the MFMAs of item i) instead of the ping-pong read / multiply parts (round 6)
+  int wide_pipe;            // TANGO_WIDE_PIPE=0|1|2    256 x 320 GEMM: in-wave software pipeline (fragments of item i+1 requested under the MFMAs of item i) instead of the ping-pong read / multiply parts; 1 = staggered halves, two barriers per item, 2 = all waves in step, one barrier per item (round 6: both slower than ping-pong on the GEMMs)
+  int conv_pipe;            // TANGO_CONV_PIPE=0..3     256 x 320 conv: 0 = ping-pong kernel, 1 / 2 as above, 3 = one barrier per item with the halves half an item apart.  Default 2 (round 6: convs -1.4 %, bit-identical)
 };
 
 inline Tuning read_tuning() {
@@ -81,6 +82,7 @@ inline Tuning read_tuning() {
   x.duo_mask = num("TANGO_DUO_MASK", 7);
   x.duo_prio = num("TANGO_DUO_PRIO", 0);
   x.wide_pipe = num("TANGO_WIDE_PIPE", 0);
+  x.conv_pipe = num("TANGO_CONV_PIPE", 2);
   x.conv_tall = num("TANGO_CONV_TALL", 0);
   x.attn_x8_qb = num("TANGO_ATTN_X8_QB", 2);
   const char* wp = getenv("TANGO_WIDE_PRIO");

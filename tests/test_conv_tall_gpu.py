@@ -14,8 +14,8 @@ from test_duo_gpu import DT, TOL, p, q, run, tuning
 pytestmark = pytest.mark.gpu
 
 REPS = int(os.environ.get("TANGO_TALL_REPS", "12"))
-TALL = dict(TANGO_CONV_TALL=1, TANGO_WIDE_PIPE=0, TANGO_FORCE_DMA_GEMM=1)
-WIDE = dict(TANGO_CONV_TALL=0, TANGO_WIDE_PIPE=0, TANGO_FORCE_DMA_GEMM=1)
+TALL = dict(TANGO_CONV_TALL=1, TANGO_CONV_PIPE=0, TANGO_FORCE_DMA_GEMM=1)
+WIDE = dict(TANGO_CONV_TALL=0, TANGO_CONV_PIPE=0, TANGO_FORCE_DMA_GEMM=1)
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
@@ -58,9 +58,10 @@ def test_unet_forward_tall_equals_wide(lib):
     e = Engine(unet=UNET_CONFIG_LARGE, dtype="fp16")
     e.load_synthetic(1234)
     outs = []
-    for env in (dict(TANGO_CONV_TALL=0), dict(TANGO_CONV_TALL=1)):
+    for env in (dict(TANGO_CONV_TALL=0, TANGO_CONV_PIPE=0), dict(TANGO_CONV_TALL=1), dict(TANGO_CONV_TALL=0, TANGO_CONV_PIPE=2)):
         with tuning(lib, **env):
             e.drop_plans()
             outs.append(e.unet_forward(x, 500, enc, mask).clone())
     e.drop_plans()
     assert torch.equal(outs[0], outs[1]), "%d elements differ" % (outs[0] != outs[1]).sum().item()
+    assert torch.equal(outs[0], outs[2]), "default (in-step pipelined) conv vs ping-pong: %d elements differ" % (outs[0] != outs[2]).sum().item()

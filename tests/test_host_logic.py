@@ -434,7 +434,7 @@ def test_hot_kernels_do_not_spill():
     assert len(res) > 200
     # kernels are matched by their DEMANGLED name and template arguments (KR.template_args), not by mangled-suffix substrings
     parsed = {k: KR.template_args(k) for k in res}
-    HOT = ("conv3x3_wide_kernel", "gemm_wide_pers_kernel", "attn_kernel", "xattn_block_kernel", "conv3x3_halo_kernel", "gemm_dma_kernel",
+    HOT = ("conv3x3_wide_kernel", "conv3x3_wide_pipe_kernel", "gemm_wide_pers_kernel", "attn_kernel", "xattn_block_kernel", "conv3x3_halo_kernel", "gemm_dma_kernel",
            "gn_apply_kernel", "gn_stats_kernel")
     hot = [k for k, (name, args) in parsed.items()
            if name in HOT or (name == "lin_stream_kernel" and args and len(args) == 6 and args[5] == 1)]     # <T, KS, TN, LN, FIX, SPEC = 1>

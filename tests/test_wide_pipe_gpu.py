@@ -17,9 +17,13 @@ pytestmark = pytest.mark.gpu
 
 REPS = int(os.environ.get("TANGO_PIPE_REPS", "12"))
 PIPE = dict(TANGO_WIDE_PIPE=1, TANGO_DUO_MAXK=0, TANGO_FORCE_DMA_GEMM=1)
+CONV_PING = dict(TANGO_CONV_PIPE=0, TANGO_CONV_TALL=0, TANGO_FORCE_DMA_GEMM=1)
+# 2 = the same pipeline with all eight waves in step and ONE barrier per item (no stagger, no mid-item barrier)
+MODES = [1, 2]
 PING = dict(TANGO_WIDE_PIPE=0, TANGO_WIDE_PERS=0, TANGO_DUO_MAXK=0, TANGO_FORCE_DMA_GEMM=1)
 
 
+@pytest.mark.parametrize("pipe", MODES)
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
 @pytest.mark.parametrize("M,N,K,res,geglu", [
     (512, 320, 128, 1, 0),          # two tiles, four k-chunks: prologue + peeled last item only
@@ -30,7 +34,7 @@ PING = dict(TANGO_WIDE_PIPE=0, TANGO_WIDE_PERS=0, TANGO_DUO_MAXK=0, TANGO_FORCE_
     (262144, 320, 320, 1, 0),       # the level-0 linears
     (262144, 320, 1280, 1, 0),      # level-0 ff.net.2
 ])
-def test_wide_pipe_linear_bit_equal(lib, dtype, M, N, K, res, geglu):
+def test_wide_pipe_linear_bit_equal(lib, pipe, dtype, M, N, K, res, geglu):
     g = torch.Generator().manual_seed(M + N + K + res)
     x = q(torch.randn(M, K, generator=g), dtype).cuda()
     w = q(torch.randn(N, K, generator=g) / K ** 0.5, dtype).cuda()
@@ -40,7 +44,7 @@ def test_wide_pipe_linear_bit_equal(lib, dtype, M, N, K, res, geglu):
     call = lambda out: lib.tango_op_linear(DT[dtype], p(x), p(w), p(b), p(r), p(out), M, N, K, 0, 0, geglu, None)
     with tuning(lib, **PING):
         ref = run(lib, call, (M, No))
-    with tuning(lib, **PIPE):
+    with tuning(lib, **dict(PIPE, TANGO_WIDE_PIPE=pipe)):
         out = run(lib, call, (M, No), REPS)
     assert torch.equal(out, ref), "pipelined vs ping-pong 256x320 kernel: %d elements differ" % (out != ref).sum().item()
     h = F.linear(x, w, b)
@@ -52,9 +56,10 @@ def test_wide_pipe_linear_bit_equal(lib, dtype, M, N, K, res, geglu):
     assert err <= TOL[dtype], err
 
 
+@pytest.mark.parametrize("pipe", MODES)
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
 @pytest.mark.parametrize("M,N,K,geglu,res", [(131072, 960, 320, 0, 1), (65536, 1920, 640, 0, 0), (32768, 5120, 640, 1, 0), (16384, 10240, 1280, 1, 0)])
-def test_wide_pipe_linear_ln_bit_equal(lib, dtype, M, N, K, geglu, res):
+def test_wide_pipe_linear_ln_bit_equal(lib, pipe, dtype, M, N, K, geglu, res):
     """folded LayerNorm: in-loop statistics (plain / residual epilogue) and the external-statistics GEGLU form (levels 1-2)"""
     g = torch.Generator().manual_seed(M + N + K)
     x = q(torch.randn(M, K, generator=g) * 1.3 + 0.7, dtype).cuda()
@@ -66,14 +71,15 @@ def test_wide_pipe_linear_ln_bit_equal(lib, dtype, M, N, K, geglu, res):
     call = lambda out: lib.tango_op_linear_ln(DT[dtype], p(x), p(w), p(b), p(ga), p(be), p(r), p(out), M, N, K, geglu, C.c_float(1e-5), None)
     with tuning(lib, **PING):
         ref = run(lib, call, (M, No))
-    with tuning(lib, **PIPE):
+    with tuning(lib, **dict(PIPE, TANGO_WIDE_PIPE=pipe)):
         out = run(lib, call, (M, No), REPS)
     assert torch.equal(out, ref), "pipelined vs ping-pong (LN): %d elements differ" % (out != ref).sum().item()
 
 
+@pytest.mark.parametrize("pipe", MODES)
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
 @pytest.mark.parametrize("B,S,Ch,K,ln", [(64, 1024, 640, 640, 1), (64, 1024, 640, 640, 0), (128, 256, 1280, 1280, 1)])
-def test_wide_pipe_qkv_vt_bit_equal(lib, dtype, B, S, Ch, K, ln):
+def test_wide_pipe_qkv_vt_bit_equal(lib, pipe, dtype, B, S, Ch, K, ln):
     g = torch.Generator().manual_seed(B + S + Ch + K)
     x = q(torch.randn(B * S, K, generator=g) * 1.2 + 0.4, dtype).cuda()
     w = q(torch.randn(3 * Ch, K, generator=g) / K ** 0.5, dtype).cuda()
@@ -89,12 +95,14 @@ def test_wide_pipe_qkv_vt_bit_equal(lib, dtype, B, S, Ch, K, ln):
 
     with tuning(lib, **PING):
         ref = once()
-    with tuning(lib, **PIPE):
+    with tuning(lib, **dict(PIPE, TANGO_WIDE_PIPE=pipe)):
         for rep in range(REPS):
             o = once()
             assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]), "repetition %d differs from the ping-pong kernel" % rep
 
 
+# 3 = the conv's SKEW form: one barrier per item, the halves meet it at different column groups (half an item apart)
+@pytest.mark.parametrize("pipe", MODES + [3])
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
 @pytest.mark.parametrize("B,Cin,H,W,Cout", [
     (2, 128, 256, 16, 320),         # 32 tiles, four channel chunks (36 items)
@@ -103,15 +111,15 @@ def test_wide_pipe_qkv_vt_bit_equal(lib, dtype, B, S, Ch, K, ln):
     (16, 1280, 64, 4, 1280),        # level 2
     (64, 1280, 32, 2, 1280),        # level 3: four images per tile
 ])
-def test_wide_pipe_conv_bit_equal(lib, dtype, B, Cin, H, W, Cout):
+def test_wide_pipe_conv_bit_equal(lib, pipe, dtype, B, Cin, H, W, Cout):
     g = torch.Generator().manual_seed(B + Cin + H + Cout)
     x = q(torch.randn(B, Cin, H, W, generator=g), dtype).cuda()
     w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5, dtype).cuda()
     b = torch.randn(Cout, generator=g).cuda()
     call = lambda out: lib.tango_op_conv2d(DT[dtype], p(x), p(w), p(b), p(out), B, Cin, H, W, Cout, 1, 0, None)
-    with tuning(lib, **PING):
+    with tuning(lib, **CONV_PING):
         ref = run(lib, call, (B, Cout, H, W))
-    with tuning(lib, **PIPE):
+    with tuning(lib, **dict(CONV_PING, TANGO_CONV_PIPE=pipe)):
         out = run(lib, call, (B, Cout, H, W), REPS)
     assert torch.equal(out, ref), "pipelined vs ping-pong wide conv: %d elements differ" % (out != ref).sum().item()
     h = F.conv2d(x, w, b, padding=1)
