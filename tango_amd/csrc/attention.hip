@@ -88,8 +88,16 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // B operand is the 32 P^T values it already holds ([key block kb = 0..7][r = 0..3] -> byte 4 kb + r), the A operand 32 e4m3 bytes of
 // one V^T row staged in that key order (two ds_read_b128).  Same roundings as F8 (e4m3 P carried as 2^8 P, e4m3 V, fp32 accumulation,
 // row sums of the rounded P on the matrix pipe): only the summation order inside the MFMA differs.
-template <typename T, int QB, bool MASKED, int NW, int MINW, bool PB = false, bool F8 = false, bool MSUM = false, bool X8 = false>
+// DEFER (round 6): deferred rescale of the online softmax for the unmasked 16-bit sites.  The running maximum is only moved when some row's
+// tile maximum exceeds it by more than 2^ATTN_DEFER_LOG2 (the exact form moved it -- and rescaled the 32 O accumulators of every row -- whenever
+// ANY of the wave's rows saw a new maximum: 45 % of the tiles of an S = 4096 site); in between P = exp2(s - m_old) may exceed 1, by at most
+// 2^8, which fp16 / bf16 P and the fp32 accumulators hold with the same RELATIVE rounding as before.  Mathematically O = (sum P V) / (sum P)
+// for any offset; the decision precedes the tile's exponentials and every P of the tile sees the same offset (the textbook order of
+// cdna_hip_programming.md T13).  Not bit-identical to the exact form: TANGO_ATTN_DEFER=0 selects that.
+static constexpr float ATTN_DEFER_LOG2 = 8.0f;
+template <typename T, int QB, bool MASKED, int NW, int MINW, bool PB = false, bool F8 = false, bool MSUM = false, bool X8 = false, bool DEFER = false>
 __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p) {
+  static_assert(!DEFER || (!MASKED && !F8 && sizeof(T) == 2), "deferred rescale: unmasked 16-bit sites (the fp8 forms carry P at 2^8 already)");
   static_assert(!X8 || (F8 && MSUM && !MASKED), "MX P.V: the unmasked fp8 variant with matrix-pipe row sums");
   static_assert(!MSUM || sizeof(T) == 2, "matrix-pipe row sums: the P^T fragments of the 16-bit engines only");
   static_assert(!PB || MASKED, "position bias rides on the masked path");
@@ -339,7 +347,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
       }
       // lazy rescale: after the first few tiles the running maximum rarely moves; when it moved for NO query of this wave
       // the O / l rescale (alpha == 1 exactly) and its exponential are skipped -- same values, 32 multiplies fewer
-      if (__builtin_amdgcn_ballot_w64(mnew > mrow[qb]) != 0ull) {
+      // (DEFER: ... moved by more than 2^8 for no query; the offset of this tile's exponentials is then the OLD maximum)
+      const bool move = DEFER ? mnew > mrow[qb] + ATTN_DEFER_LOG2 : mnew > mrow[qb];
+      if (__builtin_amdgcn_ballot_w64(move) != 0ull) {
         const float alpha = __builtin_amdgcn_exp2f(mrow[qb] - mnew);
         if (MSUM) lacc[qb] *= alpha;
         else lrow[qb] *= alpha;
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
         for (int db = 0; db < 4; ++db) oacc[qb][db] *= alpha;
       }
       float rs = 0.f;
-      const float moff = F8 ? mnew - 8.f : mnew;         // F8: P is carried as 2^8 P (<= 256 < 448 = e4m3 max); cancels in O / l
+      const float moff = DEFER ? mrow[qb] : (F8 ? mnew - 8.f : mnew);   // F8: P is carried as 2^8 P (<= 256 < 448 = e4m3 max); cancels in O / l
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -536,7 +546,9 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
     else if constexpr (sizeof(T) == 2) {
       if (p.fp8_pv && tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true, true>), grid, dim3(256), 0, s, p);
       else if (p.fp8_pv) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true>), grid, dim3(256), 0, s, p);
+      else if (tuning().attn_msum && tuning().attn_defer) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, true, false, true>), grid, dim3(256), 0, s, p);
       else if (tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, true>), grid, dim3(256), 0, s, p);
+      else if (tuning().attn_defer) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, false, false, true>), grid, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
     } else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
   } else if (tuning().attn_qb2_min_wgs > 0 &&
@@ -549,7 +561,9 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
     else if constexpr (sizeof(T) == 2) {
       if (p.fp8_pv && tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true, true>), grid, dim3(256), 0, s, p);
       else if (p.fp8_pv) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true>), grid, dim3(256), 0, s, p);
+      else if (tuning().attn_msum && tuning().attn_defer) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, true, false, true>), grid, dim3(256), 0, s, p);
       else if (tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, true>), grid, dim3(256), 0, s, p);
+      else if (tuning().attn_defer) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, false, false, true>), grid, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
     } else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
   } else {
@@ -559,7 +573,9 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
     else if constexpr (sizeof(T) == 2) {
       if (p.fp8_pv && tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true, true>), grid, dim3(256), 0, s, p);
       else if (p.fp8_pv) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true>), grid, dim3(256), 0, s, p);
+      else if (tuning().attn_msum && tuning().attn_defer) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, true, false, true>), grid, dim3(256), 0, s, p);
       else if (tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, true>), grid, dim3(256), 0, s, p);
+      else if (tuning().attn_defer) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, false, false, true>), grid, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
     } else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);
   }

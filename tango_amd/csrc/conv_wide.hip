@@ -415,7 +415,14 @@ __global__ __launch_bounds__(512) void conv3x3_wide_pipe_kernel(const GemmParams
     cc0 = (int)blockIdx.y * per;
     cc1 = cc1 < cc0 + per ? cc1 : cc0 + per;
   }
-  const int NI = (cc1 - cc0) * 9;                   // >= 9
+  const int NI = (cc1 - cc0) * 9;                   // >= 9, or 0: the last split of an uneven split-K division owns no chunk
+  if (SK && NI <= 0) {
+    // (the ping-pong kernel's loops simply do not run; this one peels its last item, so the empty split leaves here: a zero partial tile.
+    //  Found by the Music UNet at B2 = 2: Cin = 960 -> 30 chunks over 7 splits of 5)
+    __syncthreads();                                // the source-offset table above shares LDS with the epilogue's staging rows
+    wide_epilogue_raw(p, acc, (int)blockIdx.y, m0 + wm * 64, n0 + wn * (TN * 16), lane, dsm + wave * (WIDE_STAGE_BYTES + 1280));
+    return;
+  }
 
   const int half = wave >> 2;
   // LDS address of this lane's activation fragment b of (halo buffer `buf`, tap offset `toff`)

@@ -125,3 +125,29 @@ def test_wide_pipe_conv_bit_equal(lib, pipe, dtype, B, Cin, H, W, Cout):
     h = F.conv2d(x, w, b, padding=1)
     err = ((out - h).abs().max() / (h.abs().max() + 1e-9)).item()
     assert err <= TOL[dtype], err
+
+
+@pytest.mark.parametrize("pipe", MODES + [3])
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [
+    (2, 960, 256, 16, 320),         # 32 tiles -> split-K: 30 channel chunks over 7 splits of 5 -- the LAST SPLIT IS EMPTY (Music UNet, B2 = 2)
+    (2, 320, 256, 16, 320),         # 10 chunks over 2 splits
+    (2, 640, 128, 8, 640),          # 16 tiles, 20 chunks over 5 splits
+    (8, 1280, 64, 4, 1280),         # level 2 at B2 = 8: 32 tiles x 8 splits
+])
+def test_wide_pipe_conv_splitk(lib, pipe, dtype, B, Cin, H, W, Cout):
+    """the split-K form of the wide conv as the engine's routing picks it (no TANGO_FORCE_DMA_GEMM: that switch disables split-K), incl. a
+    division that leaves the last split without a chunk: the pipelined kernel peels its last item and must not run it on an empty split"""
+    g = torch.Generator().manual_seed(B + Cin + H + Cout)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype).cuda()
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5, dtype).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    call = lambda out: lib.tango_op_conv2d(DT[dtype], p(x), p(w), p(b), p(out), B, Cin, H, W, Cout, 1, 0, None)
+    with tuning(lib, TANGO_CONV_PIPE=0, TANGO_CONV_TALL=0):
+        ref = run(lib, call, (B, Cout, H, W))
+    with tuning(lib, TANGO_CONV_PIPE=pipe, TANGO_CONV_TALL=0):
+        out = run(lib, call, (B, Cout, H, W), REPS)
+    h = F.conv2d(x, w, b, padding=1)
+    err = ((out - h).abs().max() / (h.abs().max() + 1e-9)).item()
+    assert err <= TOL[dtype], err
+    assert torch.equal(out, ref), "pipelined vs ping-pong wide conv (split-K): %d elements differ" % (out != ref).sum().item()
