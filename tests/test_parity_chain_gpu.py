@@ -107,6 +107,15 @@ def _oracle(key):
     return _jobs[key].result()
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _shutdown_oracle_pool():
+    yield
+    global _pool
+    if _pool is not None:
+        _pool.shutdown(wait=True)
+        _pool = None
+
+
 def _chain(key, dtype):
     B, N, seed = CASES[key]
     enc, mask, lat0, noises = _inputs(B, N, seed)
