@@ -203,6 +203,10 @@ struct GemmParams {
   int rowvec_per = 1;
   void* out_lo = nullptr;
   int64_t ldo_lo = 0;
+  // Per-sample weights (round 6: GroupNorm folded into proj_in, norm.hip gn_fold_kernel): rows [s * wb_rows, (s + 1) * wb_rows) multiply with
+  // W + s * wb_stride elements (wb_rows % 256 == 0: a tile never straddles two samples).  256 x 320 GEMM kernels only.
+  int64_t wb_stride = 0;
+  int wb_rows = 0;
   // LayerNorm folded into the weights (linear_stream.hip): y = rstd*(W'x - mean*wsum) + b'
   int ln_fold = 0;
   float ln_eps = 1e-5f;
@@ -266,6 +270,11 @@ struct GroupNormParams {
 constexpr int COOP_SYNC_SLOTS = 1024;
 constexpr int coop_sync_words() { return 2 * COOP_SYNC_SLOTS + 16; }   // + [2048]: sticky timeout flag
 size_t groupnorm_ws_floats(int B, int rows, int C, int groups);
+// GroupNorm folded into the linear that consumes it (round 6): the statistics pass alone (partials as launch_groupnorm's two-launch path
+// leaves them), then per sample s: Wf[s][n][k] = round(W[n][k] * gamma[k] * rstd[s][g(k)]), bf[s][n] = b[n] + sum_k W[n][k] * beta[k]
+// - sum_k Wf[s][n][k] * mean[s][g(k)] (the mean term against the ROUNDED weights: it cancels exactly what the GEMM adds).
+int launch_gn_stats_fold(int dtype, const GroupNormParams& p, const void* W, int64_t Kp, const float* bias, int N, void* Wf, float* bf, hipStream_t s);
+bool gn_fold_ok(int dtype, const GroupNormParams& p, int N);
 int launch_groupnorm(int dtype, const GroupNormParams& p, hipStream_t s);
 
 int launch_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma,

@@ -181,6 +181,40 @@ struct Builder {
     gemm(p, stride == 2 ? "conv3x3s2" : (ups ? "conv3x3up" : "conv3x3"));
   }
 
+  // GroupNorm folded into the linear that consumes it (round 6; norm.hip gn_fold_kernel): out = proj(GroupNorm(x)) without the normalised
+  // tensor -- statistics pass, per-sample folded weights + bias vector, then the 256 x 320 / 256 x 160 GEMM on the RAW rows (GemmParams::wb_*
+  // per-sample weights, ::rowvec per-sample bias).  Returns false (nothing emitted) where the shape / route does not allow it.
+  bool linear_gn_fold(const TView& x, int B, int rows, const WNorm& gn, int groups, const WMat& w, const TView& out) {
+    GroupNormParams gp;
+    gp.x = x.p; gp.ldx = x.ld; gp.y = nullptr; gp.ldy = 0; gp.gamma = gn.g; gp.beta = gn.b;
+    gp.B = B; gp.rows = rows; gp.C = gn.C; gp.groups = groups; gp.eps = gn.eps; gp.act = ACT_NONE;
+    gp.sync = nullptr;
+    if (w.K != gn.C || !gn_fold_ok(dt, gp, w.N)) return false;
+    GemmParams p;
+    p.A = x.p; p.lda = x.ld; p.Kp = w.Kp; p.bias = nullptr;
+    p.M = B * rows; p.N = w.N; p.K = w.K; p.Cin = w.K;
+    p.mode = GATHER_1D; p.rows_pb = p.M; p.Lin = p.M; p.Lout = p.M; p.taps = 1;
+    p.out = out.p; p.ldo = out.ld;
+    p.wb_rows = rows; p.wb_stride = (int64_t)w.N * w.Kp;
+    p.rowvec_rows = p.M; p.rowvec_per = rows; p.out_lo = out.p; p.ldo_lo = out.ld;
+    const size_t m = A.mark();
+    void* Wf = A.alloc((size_t)B * w.N * w.Kp * esz);
+    float* bf = alloc_f32((size_t)B * w.N);
+    const size_t nf = groupnorm_ws_floats(B, rows, gn.C, groups);
+    float* ws = alloc_f32(nf);
+    gp.partial = ws; gp.scale_shift = nullptr;
+    p.W = Wf; p.rowvec = bf;
+    if (gemm_pick_splitk(dt, p) > 1 || !gemm_rowvec_ok(dt, p)) { A.release(m); return false; }
+    const int d = dt;
+    const void* Wsrc = w.W; const int64_t Kp = w.Kp; const float* bsrc = w.b; const int N = w.N;
+    push([=](hipStream_t s) { return launch_gn_stats_fold(d, gp, Wsrc, Kp, bsrc, N, Wf, bf, s); },
+         "groupnorm(fold) C=" + std::to_string(gn.C) + " rows=" + std::to_string(rows));
+    gemm(p, gemm_route(dt, p) == ROUTE_DUO ? "linear(duo)" : "linear(wide)");
+    // (the folded weights are consumed by the GEMM that follows on the same stream: the slab region may be reused behind it)
+    A.release(m);
+    return true;
+  }
+
   void groupnorm(const TView& x, int B, int rows, const WNorm& w, int groups, int act, const TView& out) {
     GroupNormParams p;
     p.x = x.p; p.ldx = x.ld; p.y = out.p; p.ldy = out.ld; p.gamma = w.g; p.beta = w.b;
@@ -297,9 +331,11 @@ struct Builder {
     const size_t m = A.mark();
     auto rows_from = [&](const TView& v, int64_t r0) { TView t = v; t.p = (char*)v.p + (size_t)r0 * v.ld * esz; return t; };
     TView t0 = alloc(rows_p, C);
-    groupnorm(x, Bp, HW, w.gn, groups, ACT_NONE, t0);
     TView h = alloc(rows, C);
-    linear(t0, rows_p, w.proj_in, h);
+    if (!linear_gn_fold(x, Bp, HW, w.gn, groups, w.proj_in, h)) {
+      groupnorm(x, Bp, HW, w.gn, groups, ACT_NONE, t0);
+      linear(t0, rows_p, w.proj_in, h);
+    }
     TView qkv = alloc(rows_p, 2 * C);               // [q | k]; v goes transposed into vt [B][C][HW]
     void* vt = A.alloc((size_t)rows_p * C * esz);
     GOpt nb; nb.use_bias = false;

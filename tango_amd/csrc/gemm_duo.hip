@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmParams p, co
   const int lrow = lane >> 2;
   const int pc = (lane & 3) ^ ((4 - (lrow >> 2)) & 3);
   const unsigned char* const At = (const unsigned char*)p.A + (int64_t)m0 * p.lda * (int64_t)sizeof(T);
-  const unsigned char* const Wt = (const unsigned char*)p.W + (int64_t)n0 * p.Kp * (int64_t)sizeof(T);
+  const unsigned char* const Wt = (const unsigned char*)p.W + ((int64_t)n0 * p.Kp + (p.wb_rows ? (int64_t)(m0 / p.wb_rows) * p.wb_stride : 0)) * (int64_t)sizeof(T);
   unsigned r_off[RGW];
 #pragma unroll
   for (int i = 0; i < RGW; ++i) {

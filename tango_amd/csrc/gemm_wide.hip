@@ -96,7 +96,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmParams p, cons
   const int pc = (lane & 3) ^ ((4 - (lrow >> 2)) & 3);
   // wave-uniform bases of this tile's first activation / weight row; per-lane 32-bit offsets from them (256 / 320 rows: < 4 GiB)
   const unsigned char* const At = (const unsigned char*)p.A + (int64_t)m0 * p.lda * (int64_t)sizeof(T);
-  const unsigned char* const Wt = (const unsigned char*)p.W + (int64_t)n0 * p.Kp * (int64_t)sizeof(T);
+  const unsigned char* const Wt = (const unsigned char*)p.W + ((int64_t)n0 * p.Kp + (p.wb_rows ? (int64_t)(m0 / p.wb_rows) * p.wb_stride : 0)) * (int64_t)sizeof(T);
   unsigned r_off[RGW];
 #pragma unroll
   for (int i = 0; i < RGW; ++i) {
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(512) void gemm_wide_pipe_kernel(const GemmParams p,
   const int lrow = lane >> 2;
   const int pc = (lane & 3) ^ ((4 - (lrow >> 2)) & 3);
   const unsigned char* const At = (const unsigned char*)p.A + (int64_t)m0 * p.lda * (int64_t)sizeof(T);
-  const unsigned char* const Wt = (const unsigned char*)p.W + (int64_t)n0 * p.Kp * (int64_t)sizeof(T);
+  const unsigned char* const Wt = (const unsigned char*)p.W + ((int64_t)n0 * p.Kp + (p.wb_rows ? (int64_t)(m0 / p.wb_rows) * p.wb_stride : 0)) * (int64_t)sizeof(T);
   unsigned r_off[RGW];
 #pragma unroll
   for (int i = 0; i < RGW; ++i) {
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(512) void gemm_wide_pers_kernel(const GemmParams p,
   int t = blockIdx.x, m0, n0;
   tile_origin(t, m0, n0);
   const unsigned char* At = (const unsigned char*)p.A + (int64_t)m0 * p.lda * (int64_t)sizeof(T);
-  const unsigned char* Wt = (const unsigned char*)p.W + (int64_t)n0 * p.Kp * (int64_t)sizeof(T);
+  const unsigned char* Wt = (const unsigned char*)p.W + ((int64_t)n0 * p.Kp + (p.wb_rows ? (int64_t)(m0 / p.wb_rows) * p.wb_stride : 0)) * (int64_t)sizeof(T);
   for (int c = 0; c < npro; ++c) issue_chunk(At, Wt, c);
   wait_inflight(npro - 1);                              // chunk 0 landed
   pp_barrier();
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(512) void gemm_wide_pers_kernel(const GemmParams p,
     if (has_next) {
       tile_origin(tn, m0n, n0n);
       Atn = (const unsigned char*)p.A + (int64_t)m0n * p.lda * (int64_t)sizeof(T);
-      Wtn = (const unsigned char*)p.W + (int64_t)n0n * p.Kp * (int64_t)sizeof(T);
+      Wtn = (const unsigned char*)p.W + ((int64_t)n0n * p.Kp + (p.wb_rows ? (int64_t)(m0n / p.wb_rows) * p.wb_stride : 0)) * (int64_t)sizeof(T);
       issue_chunk(Atn, Wtn, 0);
     }
     // the epilogue's per-lane indices must be recomputed per tile: derived from an opaque copy of the lane id, or hipcc hoists them out

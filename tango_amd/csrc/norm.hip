@@ -581,6 +581,98 @@ static int gn_launch(const GroupNormParams& p, hipStream_t s) {
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm folded into the linear that consumes it (round 6: Transformer2DModel.norm -> proj_in, transformer_2d.py:255-262).  GroupNorm is
+// per (sample, group) affine, so proj_in(GroupNorm(x)) = Wf_s x + bf_s with per-SAMPLE weights Wf_s[n][k] = W[n][k] gamma[k] rstd[s][g(k)]
+// and bf_s[n] = b[n] + sum_k W[n][k] beta[k] - sum_k Wf_s[n][k] mean[s][g(k)]: the normalised tensor is never written or read (one read + one
+// write of the [M, C] stream less per site).  The mean term is summed against the ROUNDED weights the GEMM multiplies with, so it cancels
+// exactly what the GEMM adds for the group means.  One wave per output row n of one sample; statistics finalised per workgroup from the
+// chunk partials exactly as gn_apply_kernel does (double, fixed order).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gn_fold_kernel(const float* __restrict__ partial, const T* __restrict__ W, int64_t Kp,
+                                                      const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, T* __restrict__ Wf, float* __restrict__ bf,
+                                                      int chunks, int groups, float eps, int rows, int C, int N) {
+  __shared__ float mean_s[256], rstd_s[256];
+  __shared__ double part_s[2][256], tot_s[2][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int cg = C / groups;
+  int lanes = 256 / groups;
+  if (lanes > 8) lanes = 8;
+  {
+    const int g = tid / lanes, sub = tid - g * lanes;
+    if (g < groups) {
+      double a = 0.0, q = 0.0;
+      for (int ch = sub; ch < chunks; ch += lanes) {
+        const f32x2 o = *(const f32x2*)(partial + (((int64_t)b * chunks + ch) * groups + g) * 2);
+        a += (double)o.x; q += (double)o.y;
+      }
+      part_s[0][tid] = a; part_s[1][tid] = q;
+    }
+    __syncthreads();
+    if (g < groups && sub == 0) {
+      double a = 0.0, q = 0.0;
+      for (int k = 0; k < lanes; ++k) { a += part_s[0][tid + k]; q += part_s[1][tid + k]; }
+      tot_s[0][g] = a; tot_s[1][g] = q;
+    }
+  }
+  __syncthreads();
+  if (tid < groups) {
+    const double n = (double)rows * cg;
+    const double mean = tot_s[0][tid] / n;
+    double var = tot_s[1][tid] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_s[tid] = (float)mean;
+    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  const T* wr = W + (int64_t)n * Kp;
+  T* wo = Wf + ((int64_t)b * N + n) * Kp;
+  float sb = 0.f, sm = 0.f;
+  for (int k = lane; k < C; k += 64) {
+    const int g = k / cg;
+    const float w = to_f(wr[k]);
+    const T wf = from_f<T>(w * (gamma[k] * rstd_s[g]));
+    wo[k] = wf;
+    sb += w * beta[k];
+    sm += to_f(wf) * mean_s[g];
+  }
+  for (int k = C + lane; k < Kp; k += 64) wo[k] = from_f<T>(0.f);
+  sb = wave_sum(sb); sm = wave_sum(sm);
+  if (lane == 0) bf[(int64_t)b * N + n] = (bias ? bias[n] : 0.f) + sb - sm;
+}
+
+bool gn_fold_ok(int dtype, const GroupNormParams& p, int N) {
+  if (dtype == DT_F32 || !tuning().gn_fold) return false;
+  constexpr int EPV = 8;
+  if (p.C % EPV != 0 || p.C > GN_MAXC || p.C % p.groups != 0 || p.groups > 256 || p.act != ACT_NONE) return false;
+  if (p.rows % 256 != 0 || p.C > 640) return false;               // tiles of 256 rows inside one sample; per-sample weights stay small (64 x 640^2 x 2 B = 52 MB)
+  // only where GroupNorm would take its two-launch path (the one-launch kernels of the small-batch path are not split)
+  return (size_t)p.B * p.rows * p.C * 2 > ((size_t)tuning().gn_small_mb << 20);
+}
+
+template <typename T>
+static int gn_stats_fold_t(const GroupNormParams& p, const void* W, int64_t Kp, const float* bias, int N, void* Wf, float* bf, hipStream_t s) {
+  const GnGeom g = gn_geom<T>(p.B, p.rows, p.C);
+  hipLaunchKernelGGL((gn_stats_kernel<T>), dim3((unsigned)g.chunks, (unsigned)p.B), dim3(256), 0, s, (const T*)p.x, p.ldx, p.partial, p.rows,
+                     p.C, p.groups, g.VPR, g.TPR, g.RPB, g.RC);
+  hipLaunchKernelGGL((gn_fold_kernel<T>), dim3((unsigned)((N + 3) / 4), (unsigned)p.B), dim3(256), 0, s, p.partial, (const T*)W, Kp, bias,
+                     p.gamma, p.beta, (T*)Wf, bf, g.chunks, p.groups, p.eps, p.rows, p.C, N);
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gn_stats_fold(int dtype, const GroupNormParams& p, const void* W, int64_t Kp, const float* bias, int N, void* Wf, float* bf, hipStream_t s) {
+  if (!gn_fold_ok(dtype, p, N)) TANGO_FAIL("gn_stats_fold: unsupported shape");
+  if (dtype == DT_F16) return gn_stats_fold_t<f16>(p, W, Kp, bias, N, Wf, bf, s);
+  return gn_stats_fold_t<bf16>(p, W, Kp, bias, N, Wf, bf, s);
+}
+
 int launch_groupnorm(int dtype, const GroupNormParams& p, hipStream_t s) {
   switch (dtype) {
     case DT_F32: return gn_launch<float>(p, s);
