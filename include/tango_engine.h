@@ -245,6 +245,12 @@ int tango_op_linear_ln(int dtype, const float* x, const float* w, const float* b
    [B][C][S]; gamma == NULL skips the LayerNorm */
 int tango_op_linear_qkv(int dtype, const float* x, const float* w, const float* gamma, const float* beta, float* out_qk,
                         float* out_vt, int B, int S, int C, int K, float eps, void* stream);
+/* the level-0 feed-forward of BasicTransformerBlock with its LayerNorm and residual (reference: diffusers attention.py:326-335 norm3 -> ff ->
+   + hidden_states, :338-387 FeedForward, :412-433 GEGLU): out [M, C] = x + W2 GEGLU(W1 LayerNorm(x) + b1) + b2, w1 [2H, C] in the reference
+   row order (value rows, then gate rows), w2 [C, H].  mode 0 = ONE launch (csrc/ff_fused.hip; C = 320, H = 1280, M % 128 == 0, 16-bit),
+   mode 1 = the engine's two-GEMM route.  reps > 0 with ms_out != NULL: mean milliseconds of `reps` repeats (HIP events) -- same-process A/B. */
+int tango_op_ff_fused(int dtype, const float* x, const float* w1, const float* b1, const float* gamma, const float* beta, const float* w2,
+                      const float* b2, float* out, int M, int C, int H, float eps, int mode, int reps, float* ms_out, void* stream);
 int tango_op_conv1d(int dtype, const float* x, const float* w, const float* bias, const float* residual, float* out, int B,
                     int Cin, int L, int Cout, int k, int dilation, int a_act, float a_slope, int e_act, float e_slope, void* stream);
 int tango_op_conv_transpose1d(int dtype, const float* x, const float* w, const float* bias, float* out, int B, int Cin, int L,

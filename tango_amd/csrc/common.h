@@ -252,6 +252,20 @@ inline bool gemm_ln_fold_ok(int dtype, const GemmParams& p) { return linear_stre
 int launch_fold_ln(int dtype, const void* W, int64_t Kp, const float* gamma, const float* beta, const float* bias_in, void* Wo,
                    float* bias_out, float* wsum, int N, int K, hipStream_t s);
 
+// ---- fused level-0 feed-forward (ff_fused.hip): out = x + W2 GEGLU(W1' LayerNorm(x) + b1') + b2 ----
+struct FFParams {
+  const void* x = nullptr; int64_t ldx = 0;      // [M][C] rows (LayerNorm input AND residual)
+  const void* w1 = nullptr; int64_t ld1 = 0;     // LayerNorm-folded GEGLU projection W' [2H][ld1], rows interleaved [16 value | 16 gate] (launch_pack perm 1 + launch_fold_ln)
+  const float* b1 = nullptr;                     // folded bias b' [2H], same row order
+  const void* w2 = nullptr; int64_t ld2 = 0;     // [C][ld2 >= H]
+  const float* b2 = nullptr;                     // [C]
+  void* out = nullptr; int64_t ldo = 0;          // [M][C]
+  int M = 0, C = 0, H = 0;
+  float eps = 1e-5f;
+};
+bool ff_fused_ok(int dtype, const FFParams& p);
+int launch_ff_fused(int dtype, const FFParams& p, hipStream_t s);
+
 // ---- norms ----
 struct GroupNormParams {
   const void* x; int64_t ldx;     // [B*rows, C]

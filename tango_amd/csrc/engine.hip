@@ -215,6 +215,21 @@ struct Builder {
     return true;
   }
 
+  // norm3 -> GEGLU projection -> ff.net.2 -> + residual of the level-0 transformer blocks in ONE launch (round 6; ff_fused.hip): the
+  // [rows, 4C] GEGLU output is never written.  Returns false (nothing emitted) where the shape does not allow it.
+  bool ff_fused(const TView& x, int64_t rows, const XfW& w, const TView& out) {
+    if (!tuning().ff_fused || !w.ff1.Wln) return false;
+    FFParams f;
+    f.x = x.p; f.ldx = x.ld; f.w1 = w.ff1.Wln; f.ld1 = w.ff1.Kp; f.b1 = w.ff1.bln; f.w2 = w.ff2.W; f.ld2 = w.ff2.Kp; f.b2 = w.ff2.b;
+    f.out = out.p; f.ldo = out.ld; f.M = (int)rows; f.C = w.C; f.H = 4 * w.C; f.eps = w.ln3.eps;
+    if (!ff_fused_ok(dt, f)) return false;
+    const int d = dt;
+    char buf[96];
+    snprintf(buf, sizeof buf, "ff_fused M=%d C=%d", f.M, f.C);
+    push([f, d](hipStream_t s) { return launch_ff_fused(d, f, s); }, buf, 2.0 * rows * (double)(8 * w.C) * w.C + 2.0 * rows * (double)(4 * w.C) * w.C);
+    return true;
+  }
+
   void groupnorm(const TView& x, int B, int rows, const WNorm& w, int groups, int act, const TView& out) {
     GroupNormParams p;
     p.x = x.p; p.ldx = x.ld; p.y = out.p; p.ldy = out.ld; p.gamma = w.g; p.beta = w.b;
@@ -399,10 +414,12 @@ struct Builder {
         { GOpt o; o.residual = &h1c; linear(a, rc, w.o2, h2c, o); }
       }
     }
-    TView gg = alloc(rows, 4 * C);
-    { GOpt o; o.epi = EPI_GEGLU; o.ln = &w.ln3; linear(h2, rows, w.ff1, gg, o); }
     TView h3 = h1;                      // h1 is dead after h2 was produced
-    { GOpt o; o.residual = &h2; linear(gg, rows, w.ff2, h3, o); }
+    if (!ff_fused(h2, rows, w, h3)) {
+      TView gg = alloc(rows, 4 * C);
+      { GOpt o; o.epi = EPI_GEGLU; o.ln = &w.ln3; linear(h2, rows, w.ff1, gg, o); }
+      { GOpt o; o.residual = &h2; linear(gg, rows, w.ff2, h3, o); }
+    }
     if (shared) {
       // the residual x exists once (B / 2 samples): one launch per half, both reading it
       GOpt o; o.residual = &x;

@@ -1,0 +1,252 @@
+// Fused feed-forward of the level-0 BasicTransformerBlock (round 6):
+//     out = x + ff.net.2( GEGLU( ff.net.0.proj( LayerNorm3(x) ) ) )
+// (mustango/diffusers/src/diffusers/models/attention.py:338-387 FeedForward / :412-433 GEGLU, :326-335 norm3 + residual) in ONE launch: the
+// [M, 4C] GEGLU output (0.67 GB written + read per site at config 3, 6.7 GB per step) never reaches HBM.  C = 320, hidden H = 1280, 16-bit.
+//
+// Organisation (activation-stationary, weights streamed through LDS; the "swapped" product of attention.hip so that nothing crosses lanes
+// between the two GEMMs):
+//   * a 512-thread workgroup owns 128 rows.  Wave w = (rg = w & 3, wn = w >> 2) holds the NORMALISED rows rg*32 .. +31 as MFMA B-operand
+//     fragments in registers for the whole kernel (LayerNorm3 is applied once, on the way in: two-pass fp32 statistics, one rounding to T --
+//     the folded weights W' = W gamma, b' = b + W beta of the engine's other LayerNorm-folded linears are multiplied with (x - mean) rstd).
+//   * the hidden dimension is walked in 40 chunks of 32 units.  GEMM 1 of chunk c, H^T = W1'(c) x^T: each wave of a pair computes 16 of the
+//     32 hidden units (value tile + gate tile, 40 MFMAs), applies bias + GEGLU in registers and leaves its 4 packed outputs per row in LDS
+//     next to its partner's, in the order the second product's B operand wants them (hidden 32c + 8g + 4wn + r: the k-slot order is
+//     arranged by CHOOSING which weight rows the LDS-DMA puts at which tile row -- no permuted weight copy, no cross-lane traffic).
+//   * GEMM 2 of chunk c - 1, out^T += W2(c-1) P^T: each wave owns 160 of the 320 output columns for its 32 rows (20 MFMAs, 80 accumulator
+//     registers); it runs in the same iteration as GEMM 1 of chunk c, so the GEGLU VALU work has independent MFMAs beside it.
+//   * weights arrive by LDS-DMA (global_load_lds, 16 rows x 64 B per instruction, source-side XOR swizzle as in gemm_wide.hip) as bundles
+//     {W1'(c): 64 rows x 640 B, W2(c-1): 320 rows x 64 B} = 60 KB, two stages; ONE workgroup barrier per iteration (60 MFMAs per wave).
+//   * epilogue: + bias + residual (the raw x rows, re-read) -> one rounding, 8-byte stores in the accumulator layout.
+// LDS: 2 x 60 KB stages + 16 KB P exchange (two parities) + 10 KB bias = 146 KB: one workgroup per CU, two waves per SIMD.
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "tuning.h"
+#include "gemm_device.h"
+
+namespace tango {
+
+namespace {
+constexpr int FF_C = 320, FF_H = 1280, FF_BM = 128;
+constexpr int FF_KS = FF_C / 32;                 // k-steps of GEMM 1
+constexpr int FF_NCH = FF_H / 32;                // hidden chunks
+constexpr int FF_STAGE = 60 * 1024;
+constexpr int FF_PBUF = 8 * 1024;                // one parity of the P exchange: [rg 4][rt 2][l15 16][g 4][wn 2] x 8 B
+constexpr int FF_LDS = 2 * FF_STAGE + 2 * FF_PBUF + 2 * FF_H * 4;
+}  // namespace
+
+template <typename T>
+__global__ __launch_bounds__(512) void ff_fused_kernel(const FFParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  unsigned char* const pbuf = dsm + 2 * FF_STAGE;
+  float* const b1s = (float*)(dsm + 2 * FF_STAGE + 2 * FF_PBUF);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wave & 3, wn = wave >> 2;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * FF_BM;
+
+  // ---- LDS-DMA sources: 60 groups of 16 rows x 64 B per bundle; wave w issues groups w + 8 i.  i < 5: W1' (group = tile * 10 + k-step,
+  // tile = 2 wn' + gate), i >= 5: W2 (group - 40 = 16-row block of output columns).  Tile row m of (wn', gate) is the weight row of hidden
+  // unit 32 c + 8 (m >> 2) + 4 wn' + (m & 3); the packed matrix interleaves [16 value | 16 gate] rows per 16 hidden units (engine.hip reg_xf).
+  const int lrow = lane >> 2;
+  const int pc = (lane & 3) ^ ((4 - (lrow >> 2)) & 3);
+  unsigned r_off[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int grp = wave + 8 * i;
+    if (i < 5) {
+      const int tile = grp / FF_KS, ks = grp - tile * FF_KS;
+      const int twn = tile >> 1, gate = tile & 1;
+      const int rowc = (lrow >> 3) * 32 + gate * 16 + ((lrow >> 2) & 1) * 8 + twn * 4 + (lrow & 3);
+      r_off[i] = (unsigned)((int64_t)rowc * p.ld1 * (int64_t)sizeof(T)) + ks * 64 + pc * 16;
+    } else {
+      r_off[i] = (unsigned)((int64_t)((grp - 40) * 16 + lrow) * p.ld2 * (int64_t)sizeof(T)) + pc * 16;
+    }
+  }
+  const bool has8 = wave < 4;                     // group w + 56 < 60
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
+  const unsigned char* const W1b = (const unsigned char*)p.w1;
+  const unsigned char* const W2b = (const unsigned char*)p.w2;
+  auto dma = [&](const int i, const unsigned char* src, const unsigned ldst) {
+    unsigned o = r_off[i];
+    asm volatile("" : "+v"(o));
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + o), (lptr_t)(uintptr_t)(ldst + (unsigned)i * 8192u), 16, 0, 0);
+  };
+  // bundle cb = {W1'(cb) if cb < NCH, W2(cb - 1) if cb >= 1} into stage cb & 1
+  auto issue_bundle = [&](const int cb) {
+    const unsigned ldst = lds0 + (unsigned)(cb & 1) * FF_STAGE + (unsigned)wave * 1024u;
+    const unsigned char* s1 = W1b + (int64_t)cb * 64 * p.ld1 * (int64_t)sizeof(T);
+    const unsigned char* s2 = W2b + (int64_t)(cb - 1) * 64;
+    if (cb < FF_NCH) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) dma(i, s1, ldst);
+    }
+    if (cb >= 1) {
+      dma(5, s2, ldst);
+      dma(6, s2, ldst);
+      if (has8) dma(7, s2, ldst);
+    }
+  };
+
+  issue_bundle(0);
+  // folded bias b' (2H floats, packed order) -> LDS
+  for (int i = tid; i < 2 * FF_H / 4; i += 512) *(f32x4*)(b1s + i * 4) = *(const f32x4*)(p.b1 + i * 4);
+
+  // ---- this wave's 32 rows: load, LayerNorm (two-pass fp32), keep as B-operand fragments ----
+  u32x4 xf[2][FF_KS];
+  {
+    const T* X = (const T*)p.x;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const T* xr = X + (int64_t)(m0 + rg * 32 + rt * 16 + l15) * p.ldx + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < FF_KS; ++ks) xf[rt][ks] = *(const u32x4*)(xr + ks * 32);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      float s = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < FF_KS; ++ks) {
+        T e[8];
+        __builtin_memcpy(e, &xf[rt][ks], 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += to_f(e[j]);
+      }
+      s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+      const float mean = s * (1.0f / FF_C);
+      float q = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < FF_KS; ++ks) {
+        T e[8];
+        __builtin_memcpy(e, &xf[rt][ks], 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = to_f(e[j]) - mean; q += d * d; }
+      }
+      q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+      const float rstd = 1.0f / sqrtf(q * (1.0f / FF_C) + p.eps);
+#pragma unroll
+      for (int ks = 0; ks < FF_KS; ++ks) {
+        T e[8];
+        __builtin_memcpy(e, &xf[rt][ks], 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = from_f<T>((to_f(e[j]) - mean) * rstd);
+        __builtin_memcpy(&xf[rt][ks], e, 16);
+      }
+    }
+  }
+
+  f32x4 oacc[10][2];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) { oacc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int foff = l15 * 64 + ((g ^ ((4 - (l15 >> 2)) & 3)) * 16);
+  const int w1off = (wn * 2 * FF_KS) * 1024 + foff;                 // value tile of this wave; gate tile FF_KS groups further
+  const int w2off = (40 + wn * 10) * 1024 + foff;
+  const int poff = ((rg * 2) * 64 + l15 * 4 + g) * 16;              // + rt * 1024
+  // bias of this lane's 4 hidden units per chunk: packed index (2c + (g >> 1)) * 32 + gate * 16 + (g & 1) * 8 + wn * 4
+  const int boff = (g >> 1) * 32 + (g & 1) * 8 + wn * 4;
+
+  // one iteration: GEMM 1 of chunk c (D1), GEMM 2 of chunk c - 1 (D2)
+  auto iter = [&](const int c, auto d1, auto d2) {
+    constexpr bool D1 = decltype(d1)::value, D2 = decltype(d2)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMAs of bundle c (issued one iteration ago) have landed
+    __syncthreads();
+    if (c + 1 <= FF_NCH) issue_bundle(c + 1);
+    const unsigned char* const St = dsm + (c & 1) * FF_STAGE;
+    f32x4 hv[2], hg[2];
+    if (D1) {
+      hv[0] = hv[1] = hg[0] = hg[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < FF_KS; ++ks) {
+        const u32x4 wv = *(const u32x4*)(St + w1off + ks * 1024);
+        const u32x4 wg = *(const u32x4*)(St + w1off + (FF_KS + ks) * 1024);
+        Mma<T>::run(hv[0], wv, xf[0][ks]);
+        Mma<T>::run(hg[0], wg, xf[0][ks]);
+        Mma<T>::run(hv[1], wv, xf[1][ks]);
+        Mma<T>::run(hg[1], wg, xf[1][ks]);
+      }
+    }
+    if (D2) {
+      const unsigned char* const Pb = pbuf + ((c - 1) & 1) * FF_PBUF + poff;
+      const u32x4 pf0 = *(const u32x4*)(Pb), pf1 = *(const u32x4*)(Pb + 1024);
+#pragma unroll
+      for (int t = 0; t < 10; ++t) {
+        const u32x4 w2f = *(const u32x4*)(St + w2off + t * 1024);
+        Mma<T>::run(oacc[t][0], w2f, pf0);
+        Mma<T>::run(oacc[t][1], w2f, pf1);
+      }
+    }
+    if (D1) {
+      const f32x4 bv = *(const f32x4*)(b1s + c * 64 + boff), bg = *(const f32x4*)(b1s + c * 64 + boff + 16);
+      unsigned char* const Pw = pbuf + (c & 1) * FF_PBUF + poff + wn * 8;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        f32x4 v = hv[rt] + bv;
+        const f32x4 gt4 = hg[rt] + bg;
+        const float gt[4] = {gt4[0], gt4[1], gt4[2], gt4[3]};
+        glu_gate4<T>(v, gt, 0);
+        T h4[4] = {from_f<T>(v[0]), from_f<T>(v[1]), from_f<T>(v[2]), from_f<T>(v[3])};
+        u32x2 w;
+        __builtin_memcpy(&w, h4, 8);
+        *(u32x2*)(Pw + rt * 1024) = w;
+      }
+    }
+  };
+
+  iter(0, std::true_type{}, std::false_type{});
+  for (int c = 1; c < FF_NCH; ++c) iter(c, std::true_type{}, std::true_type{});
+  iter(FF_NCH, std::false_type{}, std::true_type{});
+
+  // ---- epilogue: + bias + residual (the raw rows), one rounding ----
+  {
+    const T* X = (const T*)p.x;
+    T* O = (T*)p.out;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int64_t row = m0 + rg * 32 + rt * 16 + l15;
+#pragma unroll
+      for (int t = 0; t < 10; ++t) {
+        const int col = wn * 160 + t * 16 + g * 4;
+        const f32x4 b = *(const f32x4*)(p.b2 + col);
+        const u32x2 rw = *(const u32x2*)(X + row * p.ldx + col);
+        T r4[4];
+        __builtin_memcpy(r4, &rw, 8);
+        const f32x4 a = oacc[t][rt];
+        T o4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[r] = from_f<T>((a[r] + b[r]) + to_f(r4[r]));
+        u32x2 ow;
+        __builtin_memcpy(&ow, o4, 8);
+        *(u32x2*)(O + row * p.ldo + col) = ow;
+      }
+    }
+  }
+}
+
+bool ff_fused_ok(int dtype, const FFParams& p) {
+  if (dtype != DT_F16 && dtype != DT_BF16) return false;
+  if (p.C != FF_C || p.H != FF_H || p.M <= 0 || p.M % FF_BM != 0) return false;
+  if (p.ld1 != FF_C || p.ld2 != FF_H || p.ldx % 8 != 0 || p.ldo % 4 != 0) return false;
+  if (((uintptr_t)p.x | (uintptr_t)p.w1 | (uintptr_t)p.w2 | (uintptr_t)p.b1 | (uintptr_t)p.b2) & 15) return false;
+  if ((uintptr_t)p.out & 7) return false;
+  return true;
+}
+
+template <typename T> static int ff_fused_t(const FFParams& p, hipStream_t s) {
+  TANGO_TRY(ensure_dyn_lds((const void*)ff_fused_kernel<T>, FF_LDS));
+  hipLaunchKernelGGL((ff_fused_kernel<T>), dim3((unsigned)(p.M / FF_BM)), dim3(512), FF_LDS, s, p);
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_ff_fused(int dtype, const FFParams& p, hipStream_t s) {
+  if (!ff_fused_ok(dtype, p)) TANGO_FAIL("ff_fused: unsupported shape (C = 320, H = 1280, M % 128 == 0, 16-bit)");
+  if (dtype == DT_F16) return ff_fused_t<f16>(p, s);
+  return ff_fused_t<bf16>(p, s);
+}
+
+}  // namespace tango

@@ -283,6 +283,68 @@ int tango_op_linear_qkv(int dt, const float* x, const float* w, const float* gam
   return 0;
 }
 
+int tango_op_ff_fused(int dt, const float* x, const float* w1, const float* b1, const float* gamma, const float* beta, const float* w2,
+                      const float* b2, float* out, int M, int C, int H, float eps, int mode, int reps, float* ms_out, void* stream) {
+  // out = x + ff.net.2(GEGLU(ff.net.0.proj(LayerNorm(x)))) as the engine runs the level-0 feed-forward.  mode 0: ff_fused.hip (one launch);
+  // mode 1: the two-GEMM route (LayerNorm-folded GEGLU projection + ff.net.2 with the residual epilogue).  reps > 0 and ms_out: the mean
+  // time of `reps` back-to-back repeats of the op's launches (HIP events on `stream`), for same-process A/Bs.
+  hipStream_t s = (hipStream_t)stream;
+  const size_t esz = dtype_size(dt);
+  Scratch sc;
+  const int N1 = 2 * H;
+  void* xt = sc.get((size_t)M * C * esz);
+  void* w1t = sc.get((size_t)N1 * C * esz);
+  void* w1l = sc.get((size_t)N1 * C * esz);
+  void* w2t = sc.get((size_t)C * H * esz);
+  void* ot = sc.get((size_t)M * C * esz);
+  void* gg = mode == 1 ? sc.get((size_t)M * H * esz) : nullptr;
+  float* b1t = (float*)sc.get((size_t)N1 * 4);
+  float* b1l = (float*)sc.get((size_t)N1 * 4);
+  float* ws = (float*)sc.get((size_t)N1 * 4);
+  float* b2t = (float*)sc.get((size_t)C * 4);
+  if (!xt || !w1t || !w1l || !w2t || !ot || !b1t || !b1l || !ws || !b2t || (mode == 1 && !gg)) TANGO_FAIL("op_ff_fused: alloc");
+  TANGO_TRY(launch_cast_rows(dt, x, xt, C, M, C, s));
+  TANGO_TRY(launch_pack(dt, w1, w1t, N1, 1, C, C, 0, 1, C, -1, s));
+  TANGO_TRY(launch_pack(dt, w2, w2t, C, 1, H, H, 0, 1, H, 0, s));
+  TANGO_TRY(launch_permute_geglu_bias(b1, b1t, N1, s));
+  TANGO_HIP(hipMemcpyAsync(b2t, b2, (size_t)C * 4, hipMemcpyDeviceToDevice, s));
+  TANGO_TRY(launch_fold_ln(dt, w1t, C, gamma, beta, b1t, w1l, b1l, ws, N1, C, s));
+  TANGO_TRY(gemm_init());
+  FFParams f;
+  f.x = xt; f.ldx = C; f.w1 = w1l; f.ld1 = C; f.b1 = b1l; f.w2 = w2t; f.ld2 = H; f.b2 = b2t; f.out = ot; f.ldo = C;
+  f.M = M; f.C = C; f.H = H; f.eps = eps;
+  GemmParams p1, p2;
+  p1.A = xt; p1.lda = C; p1.W = w1l; p1.Kp = C; p1.bias = b1l; p1.M = M; p1.N = N1; p1.K = C; p1.Cin = C;
+  p1.mode = GATHER_1D; p1.rows_pb = M; p1.Lin = M; p1.Lout = M; p1.out = gg; p1.ldo = H; p1.epi = EPI_GEGLU;
+  p1.ln_fold = 1; p1.ln_eps = eps; p1.wsum = ws;
+  p2.A = gg; p2.lda = H; p2.W = w2t; p2.Kp = H; p2.bias = b2t; p2.M = M; p2.N = C; p2.K = H; p2.Cin = H;
+  p2.mode = GATHER_1D; p2.rows_pb = M; p2.Lin = M; p2.Lout = M; p2.out = ot; p2.ldo = C; p2.R = xt; p2.ldr = C;
+  if (mode == 1 && !gemm_ln_fold_ok(dt, p1)) TANGO_FAIL("op_ff_fused: mode 1 needs a LayerNorm-folding GEMM for this shape");
+  auto once = [&]() -> int {
+    if (mode == 0) return launch_ff_fused(dt, f, s);
+    TANGO_TRY(launch_gemm(dt, p1, s));
+    return launch_gemm(dt, p2, s);
+  };
+  TANGO_TRY(once());
+  if (reps > 0 && ms_out) {
+    hipEvent_t e0, e1;
+    TANGO_HIP(hipEventCreate(&e0));
+    TANGO_HIP(hipEventCreate(&e1));
+    TANGO_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) TANGO_TRY(once());
+    TANGO_HIP(hipEventRecord(e1, s));
+    TANGO_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    TANGO_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / (float)reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  TANGO_TRY(to_f32(dt, ot, C, out, M, C, s));
+  TANGO_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 int tango_op_conv1d(int dt, const float* x, const float* w, const float* bias, const float* residual, float* out, int B, int Cin,
                     int L, int Cout, int k, int dilation, int a_act, float a_slope, int e_act, float e_slope, void* stream) {
   hipStream_t s = (hipStream_t)stream;
