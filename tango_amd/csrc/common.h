@@ -262,6 +262,7 @@ struct FFParams {
   void* out = nullptr; int64_t ldo = 0;          // [M][C]
   int M = 0, C = 0, H = 0;
   float eps = 1e-5f;
+  int plain_loop = 0;                            // 1: the compiler-scheduled main loop (TANGO_FF_FUSED=2: the A/B arm of the asm-pipelined LDS stream)
 };
 bool ff_fused_ok(int dtype, const FFParams& p);
 int launch_ff_fused(int dtype, const FFParams& p, hipStream_t s);

@@ -37,7 +37,24 @@ constexpr int FF_PBUF = 8 * 1024;                // one parity of the P exchange
 constexpr int FF_LDS = 2 * FF_STAGE + 2 * FF_PBUF + 2 * FF_H * 4;
 }  // namespace
 
-template <typename T>
+// LDS fragment reads the compiler does not see (hipcc waits lgkmcnt(0) at the first use of ANY ds_read result, so reads issued ahead buy
+// nothing when written in C++): "=v" destinations, waited for by a counted statement that names the pair about to be consumed "+v"
+// (cdna_hip_programming.md, asm loads form (ii)).  LDS operations return in order and nothing else of this loop counts on lgkmcnt
+// (no scalar loads inside it: checked in the .s), so lgkmcnt(N) = "all but the newest N reads have landed".
+template <int OFF> __device__ __forceinline__ void ff_lds_read(u32x4& v, const unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void ff_lds_wait(u32x4& a, u32x4& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void ff_lds_wait4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int I, int N, typename F> __device__ __forceinline__ void ff_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); ff_for<I + 1, N>(f); }
+}
+
+template <typename T, bool PLAIN>
 __global__ __launch_bounds__(512) void ff_fused_kernel(const FFParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   unsigned char* const pbuf = dsm + 2 * FF_STAGE;
@@ -54,17 +71,20 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FFParams p) {
   // unit 32 c + 8 (m >> 2) + 4 wn' + (m & 3); the packed matrix interleaves [16 value | 16 gate] rows per 16 hidden units (engine.hip reg_xf).
   const int lrow = lane >> 2;
   const int pc = (lane & 3) ^ ((4 - (lrow >> 2)) & 3);
-  unsigned r_off[8];
+  // per lane: ONE offset into W1' (row of the tile's 16 that this lane fetches, for value tile of wn' = 0) and ONE into W2; everything that
+  // depends on the group (tile, k-step, 16-row block) is wave-uniform and rides on the scalar base
+  const unsigned v_off1 = (unsigned)((int64_t)((lrow >> 3) * 32 + ((lrow >> 2) & 1) * 8 + (lrow & 3)) * p.ld1 * (int64_t)sizeof(T)) + pc * 16;
+  const unsigned v_off2 = (unsigned)((int64_t)lrow * p.ld2 * (int64_t)sizeof(T)) + pc * 16;
+  unsigned s_off[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int grp = wave + 8 * i;
     if (i < 5) {
       const int tile = grp / FF_KS, ks = grp - tile * FF_KS;
       const int twn = tile >> 1, gate = tile & 1;
-      const int rowc = (lrow >> 3) * 32 + gate * 16 + ((lrow >> 2) & 1) * 8 + twn * 4 + (lrow & 3);
-      r_off[i] = (unsigned)((int64_t)rowc * p.ld1 * (int64_t)sizeof(T)) + ks * 64 + pc * 16;
+      s_off[i] = sgpr_u32((unsigned)((int64_t)(gate * 16 + twn * 4) * p.ld1 * (int64_t)sizeof(T)) + ks * 64);
     } else {
-      r_off[i] = (unsigned)((int64_t)((grp - 40) * 16 + lrow) * p.ld2 * (int64_t)sizeof(T)) + pc * 16;
+      s_off[i] = sgpr_u32((unsigned)((int64_t)((grp - 40) * 16) * p.ld2 * (int64_t)sizeof(T)));
     }
   }
   const bool has8 = wave < 4;                     // group w + 56 < 60
@@ -72,9 +92,9 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FFParams p) {
   const unsigned char* const W1b = (const unsigned char*)p.w1;
   const unsigned char* const W2b = (const unsigned char*)p.w2;
   auto dma = [&](const int i, const unsigned char* src, const unsigned ldst) {
-    unsigned o = r_off[i];
+    unsigned o = i < 5 ? v_off1 : v_off2;
     asm volatile("" : "+v"(o));
-    __builtin_amdgcn_global_load_lds((gptr_t)(src + o), (lptr_t)(uintptr_t)(ldst + (unsigned)i * 8192u), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + s_off[i] + o), (lptr_t)(uintptr_t)(ldst + (unsigned)i * 8192u), 16, 0, 0);
   };
   // bundle cb = {W1'(cb) if cb < NCH, W2(cb - 1) if cb >= 1} into stage cb & 1
   auto issue_bundle = [&](const int cb) {
@@ -197,8 +217,105 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FFParams p) {
     }
   };
 
+  // Steady-state iteration (1 <= c < NCH), the LDS stream in inline asm through a ring of three fragment pairs, two pairs ahead of their use:
+  //   items 0..9   GEMM 1 pair of k-step j (value tile, gate tile)          -> 4 MFMAs
+  //   item  10     this lane's bias quads of chunk c (value, gate)          -> GEGLU
+  //   items 11..15 GEMM 2 pair of output tiles 2 (j - 11), 2 (j - 11) + 1   -> 4 MFMAs
+  // item j + 3 is requested right behind the consumption of item j; the P fragments of chunk c - 1 are requested first of all.  The LDS-DMAs
+  // of bundle c + 1 go out one by one behind the MFMAs of k-steps 0..7 (gemm_wide.hip SCH = 1).  DM: 2 = that bundle has both parts, 1 = W2 only.
+  auto steady = [&](const int c, auto dmc) {
+    constexpr int DM = decltype(dmc)::value;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMAs of bundle c landed, own P(c - 1) written
+    pp_barrier();
+    const unsigned sb = lds0 + (unsigned)(c & 1) * FF_STAGE;
+    const unsigned a1 = sb + (unsigned)w1off, a2 = sb + (unsigned)w2off;
+    const unsigned ap = lds0 + 2 * FF_STAGE + (unsigned)((c - 1) & 1) * FF_PBUF + (unsigned)poff;
+    const unsigned ab = lds0 + 2 * FF_STAGE + 2 * FF_PBUF + (unsigned)c * 256u + (unsigned)boff * 4u;
+    const unsigned ldst = lds0 + (unsigned)((c + 1) & 1) * FF_STAGE + (unsigned)wave * 1024u;
+    const unsigned char* const s1 = W1b + (int64_t)(c + 1) * 64 * p.ld1 * (int64_t)sizeof(T);
+    const unsigned char* const s2 = W2b + (int64_t)c * 64;
+    u32x4 pf0, pf1, ring[3][2];
+    ff_lds_read<0>(pf0, ap);
+    ff_lds_read<1024>(pf1, ap);
+    auto issue = [&](auto jc) {
+      constexpr int J = decltype(jc)::value, S = J % 3;
+      if constexpr (J < 10) {
+        ff_lds_read<J * 1024>(ring[S][0], a1);
+        ff_lds_read<(FF_KS + J) * 1024>(ring[S][1], a1);
+      } else if constexpr (J == 10) {
+        ff_lds_read<0>(ring[S][0], ab);
+        ff_lds_read<64>(ring[S][1], ab);
+      } else if constexpr (J < 16) {
+        ff_lds_read<(2 * (J - 11)) * 1024>(ring[S][0], a2);
+        ff_lds_read<(2 * (J - 11) + 1) * 1024>(ring[S][1], a2);
+      }
+    };
+    issue(std::integral_constant<int, 0>{});
+    issue(std::integral_constant<int, 1>{});
+    issue(std::integral_constant<int, 2>{});
+    f32x4 hv[2], hg[2];
+    hv[0] = hv[1] = hg[0] = hg[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ff_for<0, FF_KS>([&](auto kc) {
+      constexpr int ks = decltype(kc)::value, S = ks % 3;
+      if constexpr (ks == 0) ff_lds_wait4<4>(ring[S][0], ring[S][1], pf0, pf1);
+      else ff_lds_wait<4>(ring[S][0], ring[S][1]);
+      Mma<T>::run(hv[0], ring[S][0], xf[0][ks]);
+      Mma<T>::run(hg[0], ring[S][1], xf[0][ks]);
+      Mma<T>::run(hv[1], ring[S][0], xf[1][ks]);
+      Mma<T>::run(hg[1], ring[S][1], xf[1][ks]);
+      issue(std::integral_constant<int, ks + 3>{});
+      if constexpr (ks < 8) {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ks < 5) { if (DM == 2) dma(ks, s1, ldst); }
+        else if constexpr (ks < 7) dma(ks, s2, ldst);
+        else { if (has8) dma(7, s2, ldst); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+    // bias (item 10), then GEGLU beside the first GEMM 2 pairs
+    ff_lds_wait<4>(ring[1][0], ring[1][1]);
+    const f32x4 bv = __builtin_bit_cast(f32x4, ring[1][0]), bg = __builtin_bit_cast(f32x4, ring[1][1]);
+    f32x4 v0 = hv[0] + bv, v1 = hv[1] + bv;
+    const f32x4 g0 = hg[0] + bg, g1 = hg[1] + bg;
+    issue(std::integral_constant<int, 13>{});
+    auto gemm2 = [&](auto jc, auto nc) {
+      constexpr int J = decltype(jc)::value, S = J % 3, t0 = 2 * (J - 11), N = decltype(nc)::value;
+      ff_lds_wait<N>(ring[S][0], ring[S][1]);
+      Mma<T>::run(oacc[t0][0], ring[S][0], pf0);
+      Mma<T>::run(oacc[t0][1], ring[S][0], pf1);
+      Mma<T>::run(oacc[t0 + 1][0], ring[S][1], pf0);
+      Mma<T>::run(oacc[t0 + 1][1], ring[S][1], pf1);
+    };
+    // the P stores are asm as well and sit BEHIND the last counted wait: a compiler-placed ds_write inside the stream would be one more
+    // (uncounted) entry on lgkmcnt
+    const unsigned apw = lds0 + 2 * FF_STAGE + (unsigned)(c & 1) * FF_PBUF + (unsigned)poff + (unsigned)wn * 8u;
+    auto geglu = [&](f32x4& v, const f32x4& gt4) -> u32x2 {
+      const float gt[4] = {gt4[0], gt4[1], gt4[2], gt4[3]};
+      glu_gate4<T>(v, gt, 0);
+      T h4[4] = {from_f<T>(v[0]), from_f<T>(v[1]), from_f<T>(v[2]), from_f<T>(v[3])};
+      u32x2 w;
+      __builtin_memcpy(&w, h4, 8);
+      return w;
+    };
+    gemm2(std::integral_constant<int, 11>{}, std::integral_constant<int, 4>{});
+    issue(std::integral_constant<int, 14>{});
+    const u32x2 pw0 = geglu(v0, g0);
+    gemm2(std::integral_constant<int, 12>{}, std::integral_constant<int, 4>{});
+    issue(std::integral_constant<int, 15>{});
+    const u32x2 pw1 = geglu(v1, g1);
+    gemm2(std::integral_constant<int, 13>{}, std::integral_constant<int, 4>{});
+    gemm2(std::integral_constant<int, 14>{}, std::integral_constant<int, 2>{});
+    gemm2(std::integral_constant<int, 15>{}, std::integral_constant<int, 0>{});
+    asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:1024" ::"v"(apw), "v"(pw0), "v"(pw1) : "memory");
+  };
+
   iter(0, std::true_type{}, std::false_type{});
-  for (int c = 1; c < FF_NCH; ++c) iter(c, std::true_type{}, std::true_type{});
+  if constexpr (PLAIN) {
+    for (int c = 1; c < FF_NCH; ++c) iter(c, std::true_type{}, std::true_type{});
+  } else {
+    for (int c = 1; c < FF_NCH - 1; ++c) steady(c, std::integral_constant<int, 2>{});
+    steady(FF_NCH - 1, std::integral_constant<int, 1>{});
+  }
   iter(FF_NCH, std::false_type{}, std::true_type{});
 
   // ---- epilogue: + bias + residual (the raw rows), one rounding ----
@@ -237,8 +354,13 @@ bool ff_fused_ok(int dtype, const FFParams& p) {
 }
 
 template <typename T> static int ff_fused_t(const FFParams& p, hipStream_t s) {
-  TANGO_TRY(ensure_dyn_lds((const void*)ff_fused_kernel<T>, FF_LDS));
-  hipLaunchKernelGGL((ff_fused_kernel<T>), dim3((unsigned)(p.M / FF_BM)), dim3(512), FF_LDS, s, p);
+  if (p.plain_loop || tuning().ff_fused == 2) {
+    TANGO_TRY(ensure_dyn_lds((const void*)ff_fused_kernel<T, true>, FF_LDS));
+    hipLaunchKernelGGL((ff_fused_kernel<T, true>), dim3((unsigned)(p.M / FF_BM)), dim3(512), FF_LDS, s, p);
+  } else {
+    TANGO_TRY(ensure_dyn_lds((const void*)ff_fused_kernel<T, false>, FF_LDS));
+    hipLaunchKernelGGL((ff_fused_kernel<T, false>), dim3((unsigned)(p.M / FF_BM)), dim3(512), FF_LDS, s, p);
+  }
   TANGO_HIP(hipGetLastError());
   return 0;
 }
