@@ -50,12 +50,54 @@ template <int N> __device__ __forceinline__ void ff_lds_wait(u32x4& a, u32x4& b)
 template <int N> __device__ __forceinline__ void ff_lds_wait4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
+// v[r] *= gelu(g[r]) with common.h's exact-erf polynomial (same coefficients, same operation order per value as gelu_erf_poly2) on plain
+// v_fma_f32: four independent chains side by side.  The file is compiled with -fno-slp-vectorize so that hipcc does not pair them up again.
+__device__ __forceinline__ void ff_gelu_gate4_scalar(f32x4& v, const float (&g)[4]) {
+  float xc[4], t[4], q[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { xc[r] = __builtin_amdgcn_fmed3f(g[r], -4.25f, 4.25f); t[r] = xc[r] * xc[r]; }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) q[r] = 1.498029197e-11f + t[r] * 1.123676848e-12f;
+  constexpr float cf[8] = {-7.180728823e-09f, 3.825664002e-07f, -1.045047183e-05f, 1.811638670e-04f, -2.193588131e-03f, 1.957916536e-02f,
+                           -1.326353318e-01f, 7.977887478e-01f};
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q[r] = __builtin_fmaf(q[r], t[r], cf[k]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float e = q[r] * xc[r], h = g[r] * 0.5f;
+    v[r] = v[r] * __builtin_fmaf(h, e, h);
+  }
+}
+
 template <int I, int N, typename F> __device__ __forceinline__ void ff_for(F&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); ff_for<I + 1, N>(f); }
 }
 
-template <typename T, bool PLAIN>
+// VAR: compile-time variant bits (the shipped one is FF_VAR_DEFAULT; the others are A/B arms and timing probes, TANGO_FF_VAR):
+//   bit 0      PLAIN  the compiler-scheduled main loop instead of the asm LDS stream (TANGO_FF_FUSED=2)
+//   bits 1-3   ABL    timing probes, results WRONG: 1 = no GEGLU arithmetic (P = value + gate), 2 = no LDS-DMA in the steady state (stale
+//                     weights), 4 = no GEMM 2 MFMAs
+//   bit 4      ORDER  1 = the wn = 1 waves run GEMM 2 -> GEMM 1 -> GEGLU (out of step with their SIMD partners)
+//   bit 5      GSC    GELU polynomial on plain v_fma_f32 (four interleaved chains) instead of v_pk_fma_f32 pairs (MI355X_MICROARCH.md: packed
+//                     f32 VALU beside MFMAs is an anti-lever)
+//   bits 6-7   DPL    where the LDS-DMAs of bundle c + 1 are issued: 0 = one behind each of GEMM 1's k-steps 0..7, 1 = all of them right behind
+//                     the barrier, 2 = all of them in front of the GEGLU block
+//   bit 9      PRIO   s_setprio 1 from the barrier to the end of the iteration's MFMAs
+//   bit 10     RING4  ring of FOUR fragment pairs (three ahead of their use)
+//   bit 8      EST    epilogue through per-wave fp32 staging in LDS with 16-byte residual loads / stores (0: 8-byte accesses in the accumulator layout)
+constexpr int FF_VAR_DEFAULT = 0x120;
+template <typename T, int VAR>
 __global__ __launch_bounds__(512) void ff_fused_kernel(const FFParams p) {
+  constexpr bool PLAIN = (VAR & 1) != 0;
+  constexpr int ABL = (VAR >> 1) & 7;
+  constexpr int ORDER = (VAR >> 4) & 1;
+  constexpr bool GSC = ((VAR >> 5) & 1) != 0;
+  constexpr int DPL = (VAR >> 6) & 3;
+  constexpr bool EST = ((VAR >> 8) & 1) != 0;
+  constexpr bool PRIO = ((VAR >> 9) & 1) != 0;
+  constexpr int RD = ((VAR >> 10) & 1) ? 4 : 3;       // ring depth in pairs
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   unsigned char* const pbuf = dsm + 2 * FF_STAGE;
   float* const b1s = (float*)(dsm + 2 * FF_STAGE + 2 * FF_PBUF);
@@ -221,31 +263,53 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FFParams p) {
   //   items 0..9   GEMM 1 pair of k-step j (value tile, gate tile)          -> 4 MFMAs
   //   item  10     this lane's bias quads of chunk c (value, gate)          -> GEGLU
   //   items 11..15 GEMM 2 pair of output tiles 2 (j - 11), 2 (j - 11) + 1   -> 4 MFMAs
-  // item j + 3 is requested right behind the consumption of item j; the P fragments of chunk c - 1 are requested first of all.  The LDS-DMAs
-  // of bundle c + 1 go out one by one behind the MFMAs of k-steps 0..7 (gemm_wide.hip SCH = 1).  DM: 2 = that bundle has both parts, 1 = W2 only.
-  auto steady = [&](const int c, auto dmc) {
+  // The pair at stream position P + 3 is requested right behind the consumption of position P; the P fragments of chunk c - 1 are requested
+  // first of all.  The LDS-DMAs of bundle c + 1 go out one by one behind the MFMAs of k-steps 0..7 (gemm_wide.hip SCH = 1).
+  // DM: 2 = that bundle has both parts, 1 = W2 only.
+  // ORD (TANGO_FF_ORDER): the order of the three phases inside the barrier interval.  0: GEMM 1 -> GEGLU -> GEMM 2 for every wave.  1: the wn = 1
+  // waves run GEMM 2 -> GEMM 1 -> GEGLU instead (stream 11..15, 0..9, 10), so the two waves of a SIMD (w and w + 4) are out of step: one's GEGLU
+  // VALU block lies beside the other's MFMAs instead of beside the other's GEGLU.  Any order is correct: GEMM 2 reads P(c - 1), written before
+  // the barrier that opens the interval; P(c) only has to be written before the barrier that closes it.
+  auto steady = [&](const int c, auto dmc, auto ordc) {
     constexpr int DM = decltype(dmc)::value;
+    constexpr int ORD = decltype(ordc)::value;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMAs of bundle c landed, own P(c - 1) written
     pp_barrier();
     const unsigned sb = lds0 + (unsigned)(c & 1) * FF_STAGE;
     const unsigned a1 = sb + (unsigned)w1off, a2 = sb + (unsigned)w2off;
     const unsigned ap = lds0 + 2 * FF_STAGE + (unsigned)((c - 1) & 1) * FF_PBUF + (unsigned)poff;
     const unsigned ab = lds0 + 2 * FF_STAGE + 2 * FF_PBUF + (unsigned)c * 256u + (unsigned)boff * 4u;
+    const unsigned apw = lds0 + 2 * FF_STAGE + (unsigned)(c & 1) * FF_PBUF + (unsigned)poff + (unsigned)wn * 8u;
     const unsigned ldst = lds0 + (unsigned)((c + 1) & 1) * FF_STAGE + (unsigned)wave * 1024u;
     const unsigned char* const s1 = W1b + (int64_t)(c + 1) * 64 * p.ld1 * (int64_t)sizeof(T);
     const unsigned char* const s2 = W2b + (int64_t)c * 64;
-    u32x4 pf0, pf1, ring[3][2];
+    auto dma_all = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      if (DM == 2) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dma(i, s1, ldst);
+      }
+      dma(5, s2, ldst);
+      dma(6, s2, ldst);
+      if (has8) dma(7, s2, ldst);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    u32x4 pf0, pf1, ring[RD][2];
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
     ff_lds_read<0>(pf0, ap);
     ff_lds_read<1024>(pf1, ap);
-    auto issue = [&](auto jc) {
-      constexpr int J = decltype(jc)::value, S = J % 3;
-      if constexpr (J < 10) {
+    if constexpr (DPL == 1 && (ABL & 2) == 0) dma_all();
+    auto issue = [&](auto pc) {
+      constexpr int P = decltype(pc)::value, S = P % RD;
+      constexpr int J = ORD == 0 ? P : (P < 5 ? 11 + P : P - 5);
+      if constexpr (P >= 16) {
+      } else if constexpr (J < 10) {
         ff_lds_read<J * 1024>(ring[S][0], a1);
         ff_lds_read<(FF_KS + J) * 1024>(ring[S][1], a1);
       } else if constexpr (J == 10) {
         ff_lds_read<0>(ring[S][0], ab);
         ff_lds_read<64>(ring[S][1], ab);
-      } else if constexpr (J < 16) {
+      } else {
         ff_lds_read<(2 * (J - 11)) * 1024>(ring[S][0], a2);
         ff_lds_read<(2 * (J - 11) + 1) * 1024>(ring[S][1], a2);
       }
@@ -253,59 +317,63 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FFParams p) {
     issue(std::integral_constant<int, 0>{});
     issue(std::integral_constant<int, 1>{});
     issue(std::integral_constant<int, 2>{});
+    if constexpr (RD == 4) issue(std::integral_constant<int, 3>{});
     f32x4 hv[2], hg[2];
     hv[0] = hv[1] = hg[0] = hg[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    ff_for<0, FF_KS>([&](auto kc) {
-      constexpr int ks = decltype(kc)::value, S = ks % 3;
-      if constexpr (ks == 0) ff_lds_wait4<4>(ring[S][0], ring[S][1], pf0, pf1);
-      else ff_lds_wait<4>(ring[S][0], ring[S][1]);
-      Mma<T>::run(hv[0], ring[S][0], xf[0][ks]);
-      Mma<T>::run(hg[0], ring[S][1], xf[0][ks]);
-      Mma<T>::run(hv[1], ring[S][0], xf[1][ks]);
-      Mma<T>::run(hg[1], ring[S][1], xf[1][ks]);
-      issue(std::integral_constant<int, ks + 3>{});
-      if constexpr (ks < 8) {
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ks < 5) { if (DM == 2) dma(ks, s1, ldst); }
-        else if constexpr (ks < 7) dma(ks, s2, ldst);
-        else { if (has8) dma(7, s2, ldst); }
-        __builtin_amdgcn_sched_barrier(0);
+    u32x2 pw0, pw1;
+    ff_for<0, 16>([&](auto pc) {
+      constexpr int P = decltype(pc)::value, S = P % RD;
+      constexpr int J = ORD == 0 ? P : (P < 5 ? 11 + P : P - 5);
+      constexpr int NW = 2 * ((15 - P) < (RD - 1) ? (15 - P) : (RD - 1));     // pairs still allowed in flight behind this one
+      if constexpr (P == 0) ff_lds_wait4<NW>(ring[S][0], ring[S][1], pf0, pf1);
+      else ff_lds_wait<NW>(ring[S][0], ring[S][1]);
+      if constexpr (J < 10) {
+        Mma<T>::run(hv[0], ring[S][0], xf[0][J]);
+        Mma<T>::run(hg[0], ring[S][1], xf[0][J]);
+        Mma<T>::run(hv[1], ring[S][0], xf[1][J]);
+        Mma<T>::run(hg[1], ring[S][1], xf[1][J]);
+        issue(std::integral_constant<int, P + RD>{});
+        if constexpr (J < 8 && (ABL & 2) == 0 && DPL == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (J < 5) { if (DM == 2) dma(J, s1, ldst); }
+          else if constexpr (J < 7) dma(J, s2, ldst);
+          else { if (has8) dma(7, s2, ldst); }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if constexpr (J == 10) {
+        // bias, then GEGLU; the packed outputs wait in registers for the store behind the last counted wait (a compiler-placed ds_write
+        // inside the stream would be one more, uncounted, entry on lgkmcnt)
+        const f32x4 bv = __builtin_bit_cast(f32x4, ring[S][0]), bg = __builtin_bit_cast(f32x4, ring[S][1]);
+        f32x4 v0 = hv[0] + bv, v1 = hv[1] + bv;
+        const f32x4 g0 = hg[0] + bg, g1 = hg[1] + bg;
+        issue(std::integral_constant<int, P + RD>{});
+        if constexpr (DPL == 2 && (ABL & 2) == 0) dma_all();
+        auto geglu = [&](f32x4& v, const f32x4& gt4) -> u32x2 {
+          const float gt[4] = {gt4[0], gt4[1], gt4[2], gt4[3]};
+          if constexpr (ABL & 1) v += gt4;
+          else if constexpr (GSC) ff_gelu_gate4_scalar(v, gt);
+          else glu_gate4<T>(v, gt, 0);
+          T h4[4] = {from_f<T>(v[0]), from_f<T>(v[1]), from_f<T>(v[2]), from_f<T>(v[3])};
+          u32x2 w;
+          __builtin_memcpy(&w, h4, 8);
+          return w;
+        };
+        pw0 = geglu(v0, g0);
+        pw1 = geglu(v1, g1);
+      } else {
+        constexpr int t0 = 2 * (J - 11);
+        if constexpr (ABL & 4) {
+          oacc[t0][0][0] += __builtin_bit_cast(f32x4, ring[S][0])[0] + __builtin_bit_cast(f32x4, ring[S][1])[0];
+        } else {
+          Mma<T>::run(oacc[t0][0], ring[S][0], pf0);
+          Mma<T>::run(oacc[t0][1], ring[S][0], pf1);
+          Mma<T>::run(oacc[t0 + 1][0], ring[S][1], pf0);
+          Mma<T>::run(oacc[t0 + 1][1], ring[S][1], pf1);
+        }
+        issue(std::integral_constant<int, P + RD>{});
       }
     });
-    // bias (item 10), then GEGLU beside the first GEMM 2 pairs
-    ff_lds_wait<4>(ring[1][0], ring[1][1]);
-    const f32x4 bv = __builtin_bit_cast(f32x4, ring[1][0]), bg = __builtin_bit_cast(f32x4, ring[1][1]);
-    f32x4 v0 = hv[0] + bv, v1 = hv[1] + bv;
-    const f32x4 g0 = hg[0] + bg, g1 = hg[1] + bg;
-    issue(std::integral_constant<int, 13>{});
-    auto gemm2 = [&](auto jc, auto nc) {
-      constexpr int J = decltype(jc)::value, S = J % 3, t0 = 2 * (J - 11), N = decltype(nc)::value;
-      ff_lds_wait<N>(ring[S][0], ring[S][1]);
-      Mma<T>::run(oacc[t0][0], ring[S][0], pf0);
-      Mma<T>::run(oacc[t0][1], ring[S][0], pf1);
-      Mma<T>::run(oacc[t0 + 1][0], ring[S][1], pf0);
-      Mma<T>::run(oacc[t0 + 1][1], ring[S][1], pf1);
-    };
-    // the P stores are asm as well and sit BEHIND the last counted wait: a compiler-placed ds_write inside the stream would be one more
-    // (uncounted) entry on lgkmcnt
-    const unsigned apw = lds0 + 2 * FF_STAGE + (unsigned)(c & 1) * FF_PBUF + (unsigned)poff + (unsigned)wn * 8u;
-    auto geglu = [&](f32x4& v, const f32x4& gt4) -> u32x2 {
-      const float gt[4] = {gt4[0], gt4[1], gt4[2], gt4[3]};
-      glu_gate4<T>(v, gt, 0);
-      T h4[4] = {from_f<T>(v[0]), from_f<T>(v[1]), from_f<T>(v[2]), from_f<T>(v[3])};
-      u32x2 w;
-      __builtin_memcpy(&w, h4, 8);
-      return w;
-    };
-    gemm2(std::integral_constant<int, 11>{}, std::integral_constant<int, 4>{});
-    issue(std::integral_constant<int, 14>{});
-    const u32x2 pw0 = geglu(v0, g0);
-    gemm2(std::integral_constant<int, 12>{}, std::integral_constant<int, 4>{});
-    issue(std::integral_constant<int, 15>{});
-    const u32x2 pw1 = geglu(v1, g1);
-    gemm2(std::integral_constant<int, 13>{}, std::integral_constant<int, 4>{});
-    gemm2(std::integral_constant<int, 14>{}, std::integral_constant<int, 2>{});
-    gemm2(std::integral_constant<int, 15>{}, std::integral_constant<int, 0>{});
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:1024" ::"v"(apw), "v"(pw0), "v"(pw1) : "memory");
   };
 
@@ -313,13 +381,62 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FFParams p) {
   if constexpr (PLAIN) {
     for (int c = 1; c < FF_NCH; ++c) iter(c, std::true_type{}, std::true_type{});
   } else {
-    for (int c = 1; c < FF_NCH - 1; ++c) steady(c, std::integral_constant<int, 2>{});
-    steady(FF_NCH - 1, std::integral_constant<int, 1>{});
+    if (ORDER == 1 && wn == 1) {   // (wave-uniform)
+      for (int c = 1; c < FF_NCH - 1; ++c) steady(c, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+      steady(FF_NCH - 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    } else {
+      for (int c = 1; c < FF_NCH - 1; ++c) steady(c, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+      steady(FF_NCH - 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    }
   }
   iter(FF_NCH, std::false_type{}, std::true_type{});
 
   // ---- epilogue: + bias + residual (the raw rows), one rounding ----
-  {
+  if constexpr (EST) {
+    // per-wave fp32 staging (16 rows x 160 columns per pass, two passes) in the operand stages, then 16-byte pieces: 5 residual loads and 5
+    // stores per lane and pass instead of 10 + 10 eight-byte ones in the accumulator layout (the store tail of a row-per-lane epilogue is
+    // issue-bound, MI355X_MICROARCH.md).  Same arithmetic per element: (acc + bias) + residual -> one rounding.
+    constexpr int PITCH = 160 * 4 + 16;
+    __syncthreads();                                   // every wave is past its last fragment read
+    unsigned char* const stg = dsm + wave * (16 * PITCH);
+    const T* X = (const T*)p.x;
+    T* O = (T*)p.out;
+    int prow[5], pcol[5];
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+      const int idx = lane + it * 64;
+      prow[it] = idx / 20;
+      pcol[it] = (idx - prow[it] * 20) * 8;
+    }
+    u32x4 rv[2][5];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int it = 0; it < 5; ++it)
+        rv[rt][it] = *(const u32x4*)(X + (int64_t)(m0 + rg * 32 + rt * 16 + prow[it]) * p.ldx + wn * 160 + pcol[it]);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+      for (int t = 0; t < 10; ++t) {
+        const f32x4 b = *(const f32x4*)(p.b2 + wn * 160 + t * 16 + g * 4);
+        *(f32x4*)(stg + l15 * PITCH + (t * 16 + g * 4) * 4) = oacc[t][rt] + b;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 5; ++it) {
+        const f32x4 lo = *(const f32x4*)(stg + prow[it] * PITCH + pcol[it] * 4);
+        const f32x4 hi = *(const f32x4*)(stg + prow[it] * PITCH + pcol[it] * 4 + 16);
+        T r8[8], o8[8];
+        __builtin_memcpy(r8, &rv[rt][it], 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o8[j] = from_f<T>(lo[j] + to_f(r8[j])); o8[4 + j] = from_f<T>(hi[j] + to_f(r8[4 + j])); }
+        u32x4 ow;
+        __builtin_memcpy(&ow, o8, 16);
+        *(u32x4*)(O + (int64_t)(m0 + rg * 32 + rt * 16 + prow[it]) * p.ldo + wn * 160 + pcol[it]) = ow;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
     const T* X = (const T*)p.x;
     T* O = (T*)p.out;
 #pragma unroll
@@ -353,16 +470,37 @@ bool ff_fused_ok(int dtype, const FFParams& p) {
   return true;
 }
 
-template <typename T> static int ff_fused_t(const FFParams& p, hipStream_t s) {
-  if (p.plain_loop || tuning().ff_fused == 2) {
-    TANGO_TRY(ensure_dyn_lds((const void*)ff_fused_kernel<T, true>, FF_LDS));
-    hipLaunchKernelGGL((ff_fused_kernel<T, true>), dim3((unsigned)(p.M / FF_BM)), dim3(512), FF_LDS, s, p);
-  } else {
-    TANGO_TRY(ensure_dyn_lds((const void*)ff_fused_kernel<T, false>, FF_LDS));
-    hipLaunchKernelGGL((ff_fused_kernel<T, false>), dim3((unsigned)(p.M / FF_BM)), dim3(512), FF_LDS, s, p);
-  }
+template <typename T, int VAR> static int ff_fused_go(const FFParams& p, hipStream_t s) {
+  TANGO_TRY(ensure_dyn_lds((const void*)ff_fused_kernel<T, VAR>, FF_LDS));
+  hipLaunchKernelGGL((ff_fused_kernel<T, VAR>), dim3((unsigned)(p.M / FF_BM)), dim3(512), FF_LDS, s, p);
   TANGO_HIP(hipGetLastError());
   return 0;
+}
+
+template <typename T> static int ff_fused_t(const FFParams& p, hipStream_t s) {
+  if constexpr (__is_same(T, f16)) {
+    // A/B arms and timing probes (tools/ff_fused_ablation.py): fp16 only
+    static const int var = getenv("TANGO_FF_VAR") ? (int)strtol(getenv("TANGO_FF_VAR"), nullptr, 0) : -1;
+    switch (var) {
+      case 0x000: return ff_fused_go<f16, 0x000>(p, s);
+      case 0x010: return ff_fused_go<f16, 0x010>(p, s);
+      case 0x100: return ff_fused_go<f16, 0x100>(p, s);
+      case 0x320: return ff_fused_go<f16, 0x320>(p, s);
+      case 0x520: return ff_fused_go<f16, 0x520>(p, s);
+      case 0x720: return ff_fused_go<f16, 0x720>(p, s);
+      case 0x140: return ff_fused_go<f16, 0x140>(p, s);
+      case 0x180: return ff_fused_go<f16, 0x180>(p, s);
+      case 0x1a0: return ff_fused_go<f16, 0x1a0>(p, s);
+      case 0x122: return ff_fused_go<f16, 0x122>(p, s);
+      case 0x124: return ff_fused_go<f16, 0x124>(p, s);
+      case 0x126: return ff_fused_go<f16, 0x126>(p, s);
+      case 0x128: return ff_fused_go<f16, 0x128>(p, s);
+      case 0x12e: return ff_fused_go<f16, 0x12e>(p, s);
+      default: break;
+    }
+  }
+  if (p.plain_loop || tuning().ff_fused == 2) return ff_fused_go<T, 1>(p, s);
+  return ff_fused_go<T, FF_VAR_DEFAULT>(p, s);
 }
 
 int launch_ff_fused(int dtype, const FFParams& p, hipStream_t s) {

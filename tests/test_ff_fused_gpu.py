@@ -71,6 +71,17 @@ def test_ff_fused_matches_torch_and_two_gemm_route(lib, dtype, M, mean, outlier)
         assert torch.equal(again, fused), "repetition %d differs at %d elements" % (rep, (again != fused).sum().item())
 
 
+def test_ff_fused_main_loop_forms_agree_bitwise(lib):
+    """the asm-pipelined LDS stream + staged epilogue (shipped) and the compiler-scheduled loop + accumulator-layout epilogue (TANGO_FF_FUSED=2)
+    perform the same arithmetic in the same order per output element"""
+    M = 16384
+    t = make(M, "fp16", 77, 0.9, True)
+    a, _ = call(lib, "fp16", t, M, 0)
+    with tuning(lib, TANGO_FF_FUSED=2):
+        b, _ = call(lib, "fp16", t, M, 0)
+    assert torch.equal(a, b), "%d elements differ" % (a != b).sum().item()
+
+
 def test_ff_fused_refuses_other_shapes(lib):
     t = make(128, "fp16", 1)
     x, w1, b1, ga, be, w2, b2 = t
