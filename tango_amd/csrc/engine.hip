@@ -218,7 +218,7 @@ struct Builder {
   // norm3 -> GEGLU projection -> ff.net.2 -> + residual of the level-0 transformer blocks in ONE launch (round 6; ff_fused.hip): the
   // [rows, 4C] GEGLU output is never written.  Returns false (nothing emitted) where the shape does not allow it.
   bool ff_fused(const TView& x, int64_t rows, const XfW& w, const TView& out) {
-    if (!tuning().ff_fused || !w.ff1.Wln) return false;
+    if (!tuning().ff_fused || !w.ff1.Wln || rows < tuning().ff_min_rows) return false;
     FFParams f;
     f.x = x.p; f.ldx = x.ld; f.w1 = w.ff1.Wln; f.ld1 = w.ff1.Kp; f.b1 = w.ff1.bln; f.w2 = w.ff2.W; f.ld2 = w.ff2.Kp; f.b2 = w.ff2.b;
     f.out = out.p; f.ldo = out.ld; f.M = (int)rows; f.C = w.C; f.H = 4 * w.C; f.eps = w.ln3.eps;
