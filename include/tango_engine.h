@@ -251,6 +251,10 @@ int tango_op_linear_qkv(int dtype, const float* x, const float* w, const float* 
    mode 1 = the engine's two-GEMM route.  reps > 0 with ms_out != NULL: mean milliseconds of `reps` repeats (HIP events) -- same-process A/B. */
 int tango_op_ff_fused(int dtype, const float* x, const float* w1, const float* b1, const float* gamma, const float* beta, const float* w2,
                       const float* b2, float* out, int M, int C, int H, float eps, int mode, int reps, float* ms_out, void* stream);
+/* as tango_op_linear_qkv with LayerNorm (K = C): mode 0 = the activation-stationary kernel of the level-0 sites (csrc/ff_fused.hip
+   qkv_stat_kernel: C = 320, (B * S) % 256 == 0, S % 256 == 0, 16-bit), mode 1 = the GEMM route; reps / ms_out as tango_op_ff_fused */
+int tango_op_qkv_stat(int dtype, const float* x, const float* w, const float* gamma, const float* beta, float* out_qk, float* out_vt, int B,
+                      int S, int C, float eps, int mode, int reps, float* ms_out, void* stream);
 int tango_op_conv1d(int dtype, const float* x, const float* w, const float* bias, const float* residual, float* out, int B,
                     int Cin, int L, int Cout, int k, int dilation, int a_act, float a_slope, int e_act, float e_slope, void* stream);
 int tango_op_conv_transpose1d(int dtype, const float* x, const float* w, const float* bias, float* out, int B, int Cin, int L,

@@ -267,6 +267,20 @@ struct FFParams {
 bool ff_fused_ok(int dtype, const FFParams& p);
 int launch_ff_fused(int dtype, const FFParams& p, hipStream_t s);
 
+// ---- activation-stationary LayerNorm + linear for K = 320 (ff_fused.hip qkv_stat_kernel): y = W' LayerNorm(x) + b', columns [0, n_rm) row-major
+// into out, columns [n_rm, N) transposed into vt [M / vt_S][N - n_rm][vt_ld] ----
+struct QKVParams {
+  const void* x = nullptr; int64_t ldx = 0;      // [M][K]
+  const void* w = nullptr; int64_t ldw = 0;      // LayerNorm-folded weights W' [N][ldw] (launch_fold_ln), or plain weights with ln = 0
+  const float* b = nullptr;                      // folded bias b' [N] (may be null)
+  void* out = nullptr; int64_t ldo = 0;
+  void* vt = nullptr; int64_t vt_ld = 0; int vt_S = 0;
+  int M = 0, N = 0, K = 0, n_rm = 0;
+  int ln = 1; float eps = 1e-5f;
+};
+bool qkv_stat_ok(int dtype, const QKVParams& p);
+int launch_qkv_stat(int dtype, const QKVParams& p, hipStream_t s);
+
 // ---- norms ----
 struct GroupNormParams {
   const void* x; int64_t ldx;     // [B*rows, C]

@@ -215,6 +215,20 @@ struct Builder {
     return true;
   }
 
+  // norm1 -> [to_q | to_k | to_v^T] of the level-0 self-attention on the activation-stationary kernel (round 6; ff_fused.hip qkv_stat_kernel)
+  bool qkv_stat(const TView& x, int64_t rows, const XfW& w, const TView& qk, void* vt, int HW) {
+    if (!tuning().qkv_stat || !w.qkv.Wln || rows < tuning().qkv_min_rows) return false;
+    QKVParams q;
+    q.x = x.p; q.ldx = x.ld; q.w = w.qkv.Wln; q.ldw = w.qkv.Kp; q.b = w.qkv.bln; q.out = qk.p; q.ldo = qk.ld; q.vt = vt; q.vt_ld = HW; q.vt_S = HW;
+    q.M = (int)rows; q.N = 3 * w.C; q.K = w.C; q.n_rm = 2 * w.C; q.ln = 1; q.eps = w.ln1.eps;
+    if (!qkv_stat_ok(dt, q)) return false;
+    const int d = dt;
+    char buf[96];
+    snprintf(buf, sizeof buf, "qkv_stat M=%d N=%d K=%d", q.M, q.N, q.K);
+    push([q, d](hipStream_t s) { return launch_qkv_stat(d, q, s); }, buf, 2.0 * rows * (double)q.N * q.K);
+    return true;
+  }
+
   // norm3 -> GEGLU projection -> ff.net.2 -> + residual of the level-0 transformer blocks in ONE launch (round 6; ff_fused.hip): the
   // [rows, 4C] GEGLU output is never written.  Returns false (nothing emitted) where the shape does not allow it.
   bool ff_fused(const TView& x, int64_t rows, const XfW& w, const TView& out) {
@@ -354,7 +368,9 @@ struct Builder {
     TView qkv = alloc(rows_p, 2 * C);               // [q | k]; v goes transposed into vt [B][C][HW]
     void* vt = A.alloc((size_t)rows_p * C * esz);
     GOpt nb; nb.use_bias = false;
-    { GOpt o = nb; o.ln = &w.ln1; o.vt = vt; o.vt_n0 = 2 * C; o.vt_S = HW; o.vt_ld = HW; linear(h, rows_p, w.qkv, qkv, o); }
+    if (!qkv_stat(h, rows_p, w, qkv, vt, HW)) {
+      GOpt o = nb; o.ln = &w.ln1; o.vt = vt; o.vt_n0 = 2 * C; o.vt_S = HW; o.vt_ld = HW; linear(h, rows_p, w.qkv, qkv, o);
+    }
     TView a = alloc(rows_p, C);
     // self-attention; `unet_attn_fp8` (BASELINE config 5): P.V on the fp8 MFMA at the sites that dominate the attention time
     // (unmasked, Skv a multiple of 64); cross-attention (64 text tokens, masked) stays in the engine dtype

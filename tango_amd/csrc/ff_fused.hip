@@ -461,6 +461,224 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FFParams p) {
   }
 }
 
+// ================================================================================================================================
+// Activation-stationary LayerNorm + QKV projection of the level-0 self-attention (round 6): [q | k] row-major and v TRANSPOSED
+// ([B][C][S], the layout attention.hip stages from) out of ONE pass over x -- Attention.to_q / to_k / to_v on norm1(x),
+// mustango/diffusers/src/diffusers/models/attention.py:276-296, attention_processor.py:495-520.  K = C = 320 is ten k-steps: on the
+// 256 x 320 tile kernel the epilogue (fp32 staging, LDS transpose of the V columns) costs as much as the multiply, 573 TFLOP/s at config 3.
+// Here a 512-thread workgroup owns 256 rows, each wave keeps its 32 NORMALISED rows as MFMA operand fragments in registers for the
+// whole kernel (as ff_fused_kernel), and the [N][320] weights stream through LDS in chunks of 64 output columns (40 KB, three stages,
+// LDS-DMA; fragment stream in inline asm, ring of three k-steps).  Per chunk and wave: 80 MFMAs into 32 accumulator registers that START
+// at the folded bias, then 8 eight-byte stores straight from the accumulator layout -- inside the loop, under the next chunk's MFMAs:
+//   * q / k columns: H^T = W' x^T (A = weights, B = x): a lane holds 4 consecutive columns of one row;
+//   * v columns: the SAME two fragments with the operands exchanged, V = x W'^T (A = x, B = weights: the 16 x 16 x 32 operand layouts are
+//     mirror images), so a lane holds 4 consecutive TOKENS of one channel -- the transpose costs nothing.
+// vmcnt retires in order and counts the stores: bundle c (issued two iterations before it is read) is followed by the 8 stores of each
+// of the two chunks in between and the 5 DMAs of bundle c + 1, so `vmcnt(13)` -- the newest 13 may stay in flight -- covers it with room.
+// ================================================================================================================================
+namespace {
+constexpr int QS_BM = 256, QS_CH = 64, QS_STAGE = 40 * 1024, QS_NST = 3;
+constexpr int QS_MAXN = 1024;
+constexpr int QS_LDS = QS_NST * QS_STAGE + QS_MAXN * 4;
+}  // namespace
+
+template <int OFF> __device__ __forceinline__ void ff_lds_read32(float& v, const unsigned addr) {
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void qs_wait_frags(u32x4 (&f)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(N));
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void qkv_stat_kernel(const QKVParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  float* const bs = (float*)(dsm + QS_NST * QS_STAGE);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * QS_BM;
+  const int nch = p.N / QS_CH, nch_rm = p.n_rm / QS_CH;
+
+  // LDS-DMA: 40 groups of 16 weight rows x 64 B per chunk (group = tile * 10 + k-step), wave w issues groups w + 8 i
+  const int lrow = lane >> 2;
+  const int pc = (lane & 3) ^ ((4 - (lrow >> 2)) & 3);
+  const unsigned v_off = (unsigned)((int64_t)lrow * p.ldw * (int64_t)sizeof(T)) + pc * 16;
+  unsigned s_off[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int grp = wave + 8 * i, tile = grp / FF_KS, ks = grp - tile * FF_KS;
+    s_off[i] = sgpr_u32((unsigned)((int64_t)(tile * 16) * p.ldw * (int64_t)sizeof(T)) + ks * 64);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
+  const unsigned char* const Wb = (const unsigned char*)p.w;
+  auto dma = [&](const int i, const unsigned char* src, const unsigned ldst) {
+    unsigned o = v_off;
+    asm volatile("" : "+v"(o));
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + s_off[i] + o), (lptr_t)(uintptr_t)(ldst + (unsigned)i * 8192u), 16, 0, 0);
+  };
+  auto bundle_src = [&](const int cb) { return Wb + (int64_t)cb * QS_CH * p.ldw * (int64_t)sizeof(T); };
+  auto bundle_dst = [&](const int cb) { return lds0 + (unsigned)(cb % QS_NST) * QS_STAGE + (unsigned)wave * 1024u; };
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+    if (cb < nch) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) dma(i, bundle_src(cb), bundle_dst(cb));
+    }
+  for (int i = tid; i < p.N; i += 512) bs[i] = p.b ? p.b[i] : 0.f;
+
+  // ---- this wave's 32 rows: load, LayerNorm (two-pass fp32), keep as operand fragments ----
+  u32x4 xf[2][FF_KS];
+  {
+    const T* X = (const T*)p.x;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const T* xr = X + (int64_t)(m0 + wave * 32 + rt * 16 + l15) * p.ldx + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < FF_KS; ++ks) xf[rt][ks] = *(const u32x4*)(xr + ks * 32);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      float s = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < FF_KS; ++ks) {
+        T e[8];
+        __builtin_memcpy(e, &xf[rt][ks], 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += to_f(e[j]);
+      }
+      s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+      const float mean = s * (1.0f / FF_C);
+      float q = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < FF_KS; ++ks) {
+        T e[8];
+        __builtin_memcpy(e, &xf[rt][ks], 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = to_f(e[j]) - mean; q += d * d; }
+      }
+      q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+      const float rstd = p.ln ? 1.0f / sqrtf(q * (1.0f / FF_C) + p.eps) : 1.0f;
+      const float mu = p.ln ? mean : 0.f;
+#pragma unroll
+      for (int ks = 0; ks < FF_KS; ++ks) {
+        T e[8];
+        __builtin_memcpy(e, &xf[rt][ks], 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = from_f<T>((to_f(e[j]) - mu) * rstd);
+        __builtin_memcpy(&xf[rt][ks], e, 16);
+      }
+    }
+  }
+  const int foff = l15 * 64 + ((g ^ ((4 - (l15 >> 2)) & 3)) * 16);
+  T* const O = (T*)p.out;
+  const int bb = m0 / p.vt_S, s0 = m0 - bb * p.vt_S;
+  T* const Vt = (T*)p.vt + (int64_t)bb * (p.N - p.n_rm) * p.vt_ld + s0 + wave * 32 + g * 4;
+
+  // one chunk: 64 output columns.  VT: the transposed range.
+  auto chunk = [&](const int c, auto vtc) {
+    constexpr bool VT = decltype(vtc)::value;
+    asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)" ::: "memory");
+    pp_barrier();
+    const unsigned a = lds0 + (unsigned)(c % QS_NST) * QS_STAGE + (unsigned)foff;
+    const unsigned ab = lds0 + QS_NST * QS_STAGE + (unsigned)(c * QS_CH + (VT ? l15 : g * 4)) * 4u;
+    const bool more = c + 2 < nch;
+    const unsigned char* const src = bundle_src(c + 2);
+    const unsigned ldst = bundle_dst(c + 2);
+    f32x4 acc[4][2];
+    u32x4 ring[3][4];
+    // the bias first: row-major chunks want the quad of this lane's 4 columns per tile, transposed chunks the lane's channel per tile
+    u32x4 bq[4];
+    float bsc[4];
+    if constexpr (VT) {
+      ff_lds_read32<0>(bsc[0], ab); ff_lds_read32<64>(bsc[1], ab); ff_lds_read32<128>(bsc[2], ab); ff_lds_read32<192>(bsc[3], ab);
+    } else {
+      ff_lds_read<0>(bq[0], ab); ff_lds_read<64>(bq[1], ab); ff_lds_read<128>(bq[2], ab); ff_lds_read<192>(bq[3], ab);
+    }
+    auto issue = [&](auto kc) {
+      constexpr int K = decltype(kc)::value, S = K % 3;
+      if constexpr (K < FF_KS) {
+        ff_lds_read<(0 * FF_KS + K) * 1024>(ring[S][0], a);
+        ff_lds_read<(1 * FF_KS + K) * 1024>(ring[S][1], a);
+        ff_lds_read<(2 * FF_KS + K) * 1024>(ring[S][2], a);
+        ff_lds_read<(3 * FF_KS + K) * 1024>(ring[S][3], a);
+      }
+    };
+    issue(std::integral_constant<int, 0>{});
+    issue(std::integral_constant<int, 1>{});
+    issue(std::integral_constant<int, 2>{});
+    // bias landed (12 fragment reads may stay in flight)
+    if constexpr (VT) {
+      asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(bsc[0]), "+v"(bsc[1]), "+v"(bsc[2]), "+v"(bsc[3]));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t][0] = acc[t][1] = f32x4{bsc[t], bsc[t], bsc[t], bsc[t]};
+    } else {
+      qs_wait_frags<12>(bq);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t][0] = acc[t][1] = __builtin_bit_cast(f32x4, bq[t]);
+    }
+    ff_for<0, FF_KS>([&](auto kc) {
+      constexpr int K = decltype(kc)::value, S = K % 3;
+      constexpr int NW = 4 * ((FF_KS - 1 - K) < 2 ? (FF_KS - 1 - K) : 2);
+      qs_wait_frags<NW>(ring[S]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if constexpr (VT) {
+          Mma<T>::run(acc[t][0], xf[0][K], ring[S][t]);
+          Mma<T>::run(acc[t][1], xf[1][K], ring[S][t]);
+        } else {
+          Mma<T>::run(acc[t][0], ring[S][t], xf[0][K]);
+          Mma<T>::run(acc[t][1], ring[S][t], xf[1][K]);
+        }
+      }
+      issue(std::integral_constant<int, K + 3>{});
+      if constexpr (K < 5) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) dma(K, src, ldst);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+    // 8 eight-byte stores
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const f32x4 v = acc[t][rt];
+        T o4[4] = {from_f<T>(v[0]), from_f<T>(v[1]), from_f<T>(v[2]), from_f<T>(v[3])};
+        u32x2 ow;
+        __builtin_memcpy(&ow, o4, 8);
+        if constexpr (VT) *(u32x2*)(Vt + (int64_t)(c * QS_CH - p.n_rm + t * 16 + l15) * p.vt_ld + rt * 16) = ow;
+        else *(u32x2*)(O + (int64_t)(m0 + wave * 32 + rt * 16 + l15) * p.ldo + c * QS_CH + t * 16 + g * 4) = ow;
+      }
+    // a chunk without DMAs still has to present 13 younger operations to the next chunk's vmcnt(13): it does not (8 stores only), which
+    // makes that wait STRICTER (it then also covers older stores), never laxer
+  };
+  // (the first chunk's wait: everything of the prologue -- both bundles and the x rows -- has landed; vmcnt(13) would not cover bundle 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int c = 0; c < nch_rm; ++c) chunk(c, std::false_type{});
+  for (int c = nch_rm; c < nch; ++c) chunk(c, std::true_type{});
+}
+
+bool qkv_stat_ok(int dtype, const QKVParams& p) {
+  if (dtype != DT_F16 && dtype != DT_BF16) return false;
+  if (p.K != FF_C || p.M <= 0 || p.M % QS_BM != 0 || p.N <= 0 || p.N % QS_CH != 0 || p.N > QS_MAXN || p.n_rm < 0 || p.n_rm > p.N || p.n_rm % QS_CH != 0) return false;
+  if (p.ldw != FF_C || p.ldx % 8 != 0 || p.ldo % 4 != 0 || ((uintptr_t)p.x & 15) || ((uintptr_t)p.w & 15) || ((uintptr_t)p.out & 7)) return false;
+  if (p.n_rm < p.N && (!p.vt || p.vt_S % QS_BM != 0 || p.vt_ld % 4 != 0 || ((uintptr_t)p.vt & 7) || p.M % p.vt_S != 0)) return false;
+  return true;
+}
+
+template <typename T> static int qkv_stat_t(const QKVParams& p, hipStream_t s) {
+  TANGO_TRY(ensure_dyn_lds((const void*)qkv_stat_kernel<T>, QS_LDS));
+  hipLaunchKernelGGL((qkv_stat_kernel<T>), dim3((unsigned)(p.M / QS_BM)), dim3(512), QS_LDS, s, p);
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_qkv_stat(int dtype, const QKVParams& p, hipStream_t s) {
+  if (!qkv_stat_ok(dtype, p)) TANGO_FAIL("qkv_stat: unsupported shape (K = 320, M % 256 == 0, N % 64 == 0, 16-bit)");
+  if (dtype == DT_F16) return qkv_stat_t<f16>(p, s);
+  return qkv_stat_t<bf16>(p, s);
+}
+
 bool ff_fused_ok(int dtype, const FFParams& p) {
   if (dtype != DT_F16 && dtype != DT_BF16) return false;
   if (p.C != FF_C || p.H != FF_H || p.M <= 0 || p.M % FF_BM != 0) return false;

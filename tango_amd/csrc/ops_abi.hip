@@ -345,6 +345,57 @@ int tango_op_ff_fused(int dt, const float* x, const float* w1, const float* b1, 
   return 0;
 }
 
+int tango_op_qkv_stat(int dt, const float* x, const float* w, const float* gamma, const float* beta, float* out_qk, float* out_vt, int B, int S,
+                      int C, float eps, int mode, int reps, float* ms_out, void* stream) {
+  // LayerNorm(x [B*S, C]) @ Wqkv^T [3C, C] (no bias): q | k -> out_qk [B*S, 2C], v -> out_vt [B][C][S].  mode 0: the activation-stationary kernel
+  // (ff_fused.hip qkv_stat_kernel; C = 320), mode 1: the GEMM route the dispatcher picks (folded LayerNorm, EPI_VT).  reps / ms_out as tango_op_ff_fused.
+  hipStream_t s = (hipStream_t)stream;
+  const size_t esz = dtype_size(dt);
+  Scratch sc;
+  const int M = B * S, N = 3 * C, K = C;
+  void* xt = sc.get((size_t)M * K * esz);
+  void* wt = sc.get((size_t)N * K * esz);
+  void* wl = sc.get((size_t)N * K * esz);
+  void* qk = sc.get((size_t)M * 2 * C * esz);
+  void* vt = sc.get((size_t)B * C * S * esz);
+  float* bl = (float*)sc.get((size_t)N * 4);
+  float* ws = (float*)sc.get((size_t)N * 4);
+  if (!xt || !wt || !wl || !qk || !vt || !bl || !ws) TANGO_FAIL("op_qkv_stat: alloc");
+  TANGO_TRY(launch_cast_rows(dt, x, xt, K, M, K, s));
+  TANGO_TRY(launch_pack(dt, w, wt, N, 1, K, K, 0, 1, K, 0, s));
+  TANGO_TRY(launch_fold_ln(dt, wt, K, gamma, beta, nullptr, wl, bl, ws, N, K, s));
+  TANGO_TRY(gemm_init());
+  QKVParams q;
+  q.x = xt; q.ldx = K; q.w = wl; q.ldw = K; q.b = bl; q.out = qk; q.ldo = 2 * C; q.vt = vt; q.vt_ld = S; q.vt_S = S;
+  q.M = M; q.N = N; q.K = K; q.n_rm = 2 * C; q.ln = 1; q.eps = eps;
+  GemmParams g;
+  g.A = xt; g.lda = K; g.W = wl; g.Kp = K; g.bias = bl; g.M = M; g.N = N; g.K = K; g.Cin = K;
+  g.mode = GATHER_1D; g.rows_pb = M; g.Lin = M; g.Lout = M;
+  g.out = qk; g.ldo = 2 * C; g.epi = EPI_VT; g.vt = vt; g.vt_n0 = 2 * C; g.vt_S = S; g.vt_ld = S;
+  g.ln_fold = 1; g.ln_eps = eps; g.wsum = ws;
+  if (mode == 1 && !gemm_ln_fold_ok(dt, g)) TANGO_FAIL("op_qkv_stat: mode 1 needs a LayerNorm-folding GEMM for this shape");
+  auto once = [&]() -> int { return mode == 0 ? launch_qkv_stat(dt, q, s) : launch_gemm(dt, g, s); };
+  TANGO_TRY(once());
+  if (reps > 0 && ms_out) {
+    hipEvent_t e0, e1;
+    TANGO_HIP(hipEventCreate(&e0));
+    TANGO_HIP(hipEventCreate(&e1));
+    TANGO_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) TANGO_TRY(once());
+    TANGO_HIP(hipEventRecord(e1, s));
+    TANGO_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    TANGO_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / (float)reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  TANGO_TRY(to_f32(dt, qk, 2 * C, out_qk, M, 2 * C, s));
+  TANGO_TRY(to_f32(dt, vt, S, out_vt, B * C, S, s));
+  TANGO_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 int tango_op_conv1d(int dt, const float* x, const float* w, const float* bias, const float* residual, float* out, int B, int Cin,
                     int L, int Cout, int k, int dilation, int a_act, float a_slope, int e_act, float e_slope, void* stream) {
   hipStream_t s = (hipStream_t)stream;
