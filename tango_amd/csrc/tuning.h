@@ -95,7 +95,7 @@ inline Tuning read_tuning() {
   x.gn_fold = on("TANGO_GN_FOLD");
   x.ff_fused = num("TANGO_FF_FUSED", 1);
   x.qkv_stat = num("TANGO_QKV_STAT", 1);
-  x.qkv_min_rows = num("TANGO_QKV_MIN_ROWS", 32768);
+  x.qkv_min_rows = num("TANGO_QKV_MIN_ROWS", 65536);
   x.ff_min_rows = num("TANGO_FF_MIN_ROWS", 32768);
   const char* wp = getenv("TANGO_WIDE_PRIO");
   x.wide_prio = (wp && wp[0] >= '0' && wp[0] <= '2') ? wp[0] - '0' : 0;
