@@ -276,7 +276,9 @@ struct QKVParams {
   void* out = nullptr; int64_t ldo = 0;
   void* vt = nullptr; int64_t vt_ld = 0; int vt_S = 0;
   int M = 0, N = 0, K = 0, n_rm = 0;
-  int ln = 1; float eps = 1e-5f;
+  int ln = 1; float eps = 1e-5f;               // ln: 0 = no normalisation, 1 = LayerNorm over K inside the kernel, 2 = GroupNorm with given statistics:
+  const float* gstats = nullptr;               //   mean / rstd per (sample, group) [M / rows_ps][groups][2] (norm.hip launch_gn_stats_mr), w / b folded with its gamma / beta
+  int groups = 0, rows_ps = 0;
 };
 bool qkv_stat_ok(int dtype, const QKVParams& p);
 int launch_qkv_stat(int dtype, const QKVParams& p, hipStream_t s);
@@ -304,6 +306,9 @@ size_t groupnorm_ws_floats(int B, int rows, int C, int groups);
 // - sum_k Wf[s][n][k] * mean[s][g(k)] (the mean term against the ROUNDED weights: it cancels exactly what the GEMM adds).
 int launch_gn_stats_fold(int dtype, const GroupNormParams& p, const void* W, int64_t Kp, const float* bias, int N, void* Wf, float* bf, hipStream_t s);
 bool gn_fold_ok(int dtype, const GroupNormParams& p, int N);
+// statistics pass + finalisation: mr [B][groups][2] = mean, rstd (p.partial = workspace of groupnorm_ws_floats)
+bool gn_stats_mr_ok(int dtype, const GroupNormParams& p);
+int launch_gn_stats_mr(int dtype, const GroupNormParams& p, float* mr, hipStream_t s);
 int launch_groupnorm(int dtype, const GroupNormParams& p, hipStream_t s);
 
 int launch_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma,

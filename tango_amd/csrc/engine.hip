@@ -215,6 +215,32 @@ struct Builder {
     return true;
   }
 
+  // Transformer2DModel.norm -> proj_in at level 0 without the normalised tensor (round 6): GroupNorm statistics pass + finalisation, then the
+  // activation-stationary kernel normalises the rows it loads (ff_fused.hip qkv_stat_kernel, norm mode 2; proj_in folded with gamma / beta)
+  bool gn_proj_stat(const TView& x, int B, int rows, const XfW& w, int groups, const TView& out) {
+    if (!tuning().gn_proj_stat || !w.proj_in.Wln || (int64_t)B * rows < tuning().qkv_min_rows) return false;
+    GroupNormParams gp;
+    gp.x = x.p; gp.ldx = x.ld; gp.y = nullptr; gp.ldy = 0; gp.gamma = w.gn.g; gp.beta = w.gn.b;
+    gp.B = B; gp.rows = rows; gp.C = w.C; gp.groups = groups; gp.eps = w.gn.eps; gp.act = ACT_NONE; gp.sync = nullptr;
+    QKVParams q;
+    q.x = x.p; q.ldx = x.ld; q.w = w.proj_in.Wln; q.ldw = w.proj_in.Kp; q.b = w.proj_in.bln; q.out = out.p; q.ldo = out.ld;
+    q.M = B * rows; q.N = w.proj_in.N; q.K = w.C; q.n_rm = q.N; q.ln = 2; q.groups = groups; q.rows_ps = rows; q.eps = w.gn.eps;
+    q.gstats = (const float*)(uintptr_t)16;          // placeholder for the shape check
+    if (!gn_stats_mr_ok(dt, gp) || !qkv_stat_ok(dt, q)) return false;
+    const size_t m = A.mark();
+    float* ws = alloc_f32(groupnorm_ws_floats(B, rows, w.C, groups));
+    float* mr = alloc_f32((size_t)B * groups * 2);
+    gp.partial = ws; gp.scale_shift = nullptr;
+    q.gstats = mr;
+    const int d = dt;
+    push([=](hipStream_t s) { return launch_gn_stats_mr(d, gp, mr, s); }, "groupnorm(stats) C=" + std::to_string(w.C) + " rows=" + std::to_string(rows));
+    char buf[96];
+    snprintf(buf, sizeof buf, "linear+gn(stat) M=%d N=%d K=%d", q.M, q.N, q.K);
+    push([q, d](hipStream_t s) { return launch_qkv_stat(d, q, s); }, buf, 2.0 * q.M * (double)q.N * q.K);
+    A.release(m);      // (consumed by the launch that follows on the same stream: the region may be reused behind it)
+    return true;
+  }
+
   // norm1 -> [to_q | to_k | to_v^T] of the level-0 self-attention on the activation-stationary kernel (round 6; ff_fused.hip qkv_stat_kernel)
   bool qkv_stat(const TView& x, int64_t rows, const XfW& w, const TView& qk, void* vt, int HW) {
     if (!tuning().qkv_stat || !w.qkv.Wln || rows < tuning().qkv_min_rows) return false;
@@ -361,7 +387,7 @@ struct Builder {
     auto rows_from = [&](const TView& v, int64_t r0) { TView t = v; t.p = (char*)v.p + (size_t)r0 * v.ld * esz; return t; };
     TView t0 = alloc(rows_p, C);
     TView h = alloc(rows, C);
-    if (!linear_gn_fold(x, Bp, HW, w.gn, groups, w.proj_in, h)) {
+    if (!gn_proj_stat(x, Bp, HW, w, groups, h) && !linear_gn_fold(x, Bp, HW, w.gn, groups, w.proj_in, h)) {
       groupnorm(x, Bp, HW, w.gn, groups, ACT_NONE, t0);
       linear(t0, rows_p, w.proj_in, h);
     }
@@ -1069,6 +1095,8 @@ int Engine::finalize_weights() {
     TANGO_TRY(fold_ln(x->qkv, x->ln1));
     TANGO_TRY(fold_ln(x->q2, x->ln2));
     TANGO_TRY(fold_ln(x->ff1, x->ln3));
+    // Transformer2DModel.norm (GroupNorm) into proj_in for the activation-stationary kernel of level 0 (Builder::gn_proj_stat)
+    if (dt != DT_F32 && x->C == 320) TANGO_TRY(fold_ln(x->proj_in, x->gn));
     if (dt != DT_F32 && x->C == 320 && x->heads == 5) {     // operands of the fused cross-attention block (xattn.hip)
       if (!x->q2p) {
         x->q2p = dmalloc((size_t)x->C * x->C * esz);

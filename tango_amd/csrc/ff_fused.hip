@@ -541,6 +541,28 @@ __global__ __launch_bounds__(512) void qkv_stat_kernel(const QKVParams p) {
 #pragma unroll
       for (int ks = 0; ks < FF_KS; ++ks) xf[rt][ks] = *(const u32x4*)(xr + ks * 32);
     }
+    if (p.ln == 2) {
+      // GroupNorm with given statistics: per-channel {mean, rstd} of this workgroup's sample through the (not yet used) last operand stage
+      f32x2* const tab = (f32x2*)(dsm + (QS_NST - 1) * QS_STAGE);
+      const int smp = m0 / p.rows_ps, cg = FF_C / p.groups;
+      if (tid < FF_C) tab[tid] = *(const f32x2*)(p.gstats + ((int64_t)smp * p.groups + tid / cg) * 2);
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < FF_KS; ++ks) {
+        f32x2 mr[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mr[j] = tab[ks * 32 + g * 8 + j];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          T e[8];
+          __builtin_memcpy(e, &xf[rt][ks], 16);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = from_f<T>((to_f(e[j]) - mr[j].x) * mr[j].y);
+          __builtin_memcpy(&xf[rt][ks], e, 16);
+        }
+      }
+      __syncthreads();                                  // the table's stage may be DMA'd from the first chunk on
+    } else {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       float s = 0.f;
@@ -572,6 +594,7 @@ __global__ __launch_bounds__(512) void qkv_stat_kernel(const QKVParams p) {
         for (int j = 0; j < 8; ++j) e[j] = from_f<T>((to_f(e[j]) - mu) * rstd);
         __builtin_memcpy(&xf[rt][ks], e, 16);
       }
+    }
     }
   }
   const int foff = l15 * 64 + ((g ^ ((4 - (l15 >> 2)) & 3)) * 16);
@@ -706,6 +729,7 @@ bool qkv_stat_ok(int dtype, const QKVParams& p) {
   if (dtype != DT_F16 && dtype != DT_BF16) return false;
   if (p.K != FF_C || p.M <= 0 || p.M % QS_BM != 0 || p.N <= 0 || p.N % QS_CH != 0 || p.N > QS_MAXN || p.n_rm < 0 || p.n_rm > p.N || p.n_rm % QS_CH != 0) return false;
   if (p.ldw != FF_C || p.ldx % 8 != 0 || p.ldo % 4 != 0 || ((uintptr_t)p.x & 15) || ((uintptr_t)p.w & 15) || ((uintptr_t)p.out & 7)) return false;
+  if (p.ln == 2 && (!p.gstats || p.groups <= 0 || FF_C % p.groups != 0 || p.rows_ps % QS_BM != 0 || p.M % p.rows_ps != 0 || p.N / QS_CH < QS_NST)) return false;
   if (p.n_rm < p.N && (!p.vt || p.vt_S % QS_BM != 0 || p.vt_ld % 4 != 0 || ((uintptr_t)p.vt & 7) || p.M % p.vt_S != 0)) return false;
   return true;
 }

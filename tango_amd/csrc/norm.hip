@@ -647,6 +647,59 @@ __global__ __launch_bounds__(256) void gn_fold_kernel(const float* __restrict__ 
   if (lane == 0) bf[(int64_t)b * N + n] = (bias ? bias[n] : 0.f) + sb - sm;
 }
 
+// ------------------------------------------------------------------------------------------
+// GroupNorm statistics only (round 6): the chunk partials of gn_stats_kernel finalised to mean / rstd per (sample, group), for a consumer that
+// normalises on its own way in (ff_fused.hip qkv_stat_kernel, norm mode 2: Transformer2DModel.norm -> proj_in without the normalised tensor).
+// Same arithmetic as gn_apply_kernel's per-workgroup finalisation (double, fixed order), done ONCE per sample instead of once per workgroup.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ mr, int chunks, int groups,
+                                                          float eps, int rows, int cg) {
+  __shared__ double part_s[2][256];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  int lanes = 256 / groups;
+  if (lanes > 8) lanes = 8;
+  const int g = tid / lanes, sub = tid - g * lanes;
+  if (g < groups) {
+    double a = 0.0, q = 0.0;
+    for (int ch = sub; ch < chunks; ch += lanes) {
+      const f32x2 o = *(const f32x2*)(partial + (((int64_t)b * chunks + ch) * groups + g) * 2);
+      a += (double)o.x; q += (double)o.y;
+    }
+    part_s[0][tid] = a; part_s[1][tid] = q;
+  }
+  __syncthreads();
+  if (g < groups && sub == 0) {
+    double a = 0.0, q = 0.0;
+    for (int k = 0; k < lanes; ++k) { a += part_s[0][tid + k]; q += part_s[1][tid + k]; }
+    const double n = (double)rows * cg;
+    const double mean = a / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mr[((int64_t)b * groups + g) * 2] = (float)mean;
+    mr[((int64_t)b * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+template <typename T> static int gn_stats_mr_t(const GroupNormParams& p, float* mr, hipStream_t s) {
+  const GnGeom g = gn_geom<T>(p.B, p.rows, p.C);
+  hipLaunchKernelGGL((gn_stats_kernel<T>), dim3((unsigned)g.chunks, (unsigned)p.B), dim3(256), 0, s, (const T*)p.x, p.ldx, p.partial, p.rows,
+                     p.C, p.groups, g.VPR, g.TPR, g.RPB, g.RC);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)p.B), dim3(256), 0, s, p.partial, mr, g.chunks, p.groups, p.eps, p.rows, p.C / p.groups);
+  TANGO_HIP(hipGetLastError());
+  return 0;
+}
+
+bool gn_stats_mr_ok(int dtype, const GroupNormParams& p) {
+  constexpr int EPV = 8;
+  return dtype != DT_F32 && p.C % EPV == 0 && p.C <= GN_MAXC && p.C % p.groups == 0 && p.groups <= 256;
+}
+
+int launch_gn_stats_mr(int dtype, const GroupNormParams& p, float* mr, hipStream_t s) {
+  if (!gn_stats_mr_ok(dtype, p)) TANGO_FAIL("gn_stats_mr: unsupported shape");
+  if (dtype == DT_F16) return gn_stats_mr_t<f16>(p, mr, s);
+  return gn_stats_mr_t<bf16>(p, mr, s);
+}
+
 bool gn_fold_ok(int dtype, const GroupNormParams& p, int N) {
   if (dtype == DT_F32 || !tuning().gn_fold) return false;
   constexpr int EPV = 8;

@@ -46,6 +46,7 @@ struct Tuning {
   int ff_min_rows;          // TANGO_FF_MIN_ROWS=n      ... for at least n rows (default 32768 = one 128-row workgroup per CU: at B = 1, 64 workgroups, the two GEMMs are faster: 0.27 vs 0.41 ms per step)
   int qkv_stat;             // TANGO_QKV_STAT=0|1       level-0 norm1 + QKV projection on the activation-stationary kernel (ff_fused.hip qkv_stat_kernel, round 6) ...
   int qkv_min_rows;         // TANGO_QKV_MIN_ROWS=n     ... for at least n rows
+  int gn_proj_stat;         // TANGO_GN_PROJ_STAT=0|1   level-0 GroupNorm -> proj_in: statistics pass + the activation-stationary kernel normalising on its way in (round 6); 0 = GroupNorm kernel + GEMM
   bool gn_fold;             // TANGO_GN_FOLD=1          GroupNorm -> proj_in as ONE GEMM with per-sample folded weights at levels 0-1 (round 6: built, within tolerance, measured +-0.0 ms per step: off)
   int attn_defer;           // TANGO_ATTN_DEFER=0|1     unmasked 16-bit attention: move the running softmax maximum only when a tile exceeds it by more than 2^8 (round 6); 0 = exact lazy rescale
   int attn_x8_qb;           // TANGO_ATTN_X8_QB=1|2     MX fp8 P.V attention (unet_attn_fp8 = 2): 16 query rows per wave at three waves per SIMD, or 32 at two (round 6)
@@ -95,6 +96,7 @@ inline Tuning read_tuning() {
   x.gn_fold = on("TANGO_GN_FOLD");
   x.ff_fused = num("TANGO_FF_FUSED", 1);
   x.qkv_stat = num("TANGO_QKV_STAT", 1);
+  x.gn_proj_stat = num("TANGO_GN_PROJ_STAT", 1);
   x.qkv_min_rows = num("TANGO_QKV_MIN_ROWS", 65536);
   x.ff_min_rows = num("TANGO_FF_MIN_ROWS", 32768);
   const char* wp = getenv("TANGO_WIDE_PRIO");

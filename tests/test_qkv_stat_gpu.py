@@ -102,3 +102,41 @@ def test_unet_forward_with_qkv_stat(lib, dtype, tol):
     d = (outs[0] - outs[1]).abs().max().item() / scale
     print("UNet forward %s B2=%d: GEMM-route QKV vs oracle %.3e, activation-stationary QKV vs oracle %.3e, apart %.3e" % (dtype, B2, e0, e1, d))
     assert e0 <= tol and e1 <= tol and d <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp16", 4e-3), ("bf16", 4e-2)])
+def test_unet_forward_with_groupnorm_proj_in_on_the_stationary_kernel(lib, dtype, tol):
+    """Transformer2DModel.norm -> proj_in at level 0 (transformer_2d.py:255-262): GroupNorm statistics pass + the activation-stationary kernel
+    normalising the rows it loads (norm mode 2), against the GroupNorm kernel + GEMM route and the oracle; repeated bit-identically"""
+    from oracle import tango_oracle as O
+    from tango_amd import weights as W
+    from tango_amd.engine import UNET_CONFIG_LARGE, Engine
+    B2 = 16                                              # 65536 rows at level 0: the engine's threshold
+    g = torch.Generator().manual_seed(36)
+    x = torch.randn(B2, 8, 256, 16, generator=g)
+    x[:, 2] += 2.0                                       # group means away from zero
+    enc = torch.randn(B2, 64, 1024, generator=g)
+    mask = torch.ones(B2, 64, dtype=torch.bool)
+    e = Engine(unet=UNET_CONFIG_LARGE, dtype=dtype)
+    e.load_synthetic(1234)
+    outs = {}
+    for on in (0, 1):
+        with tuning(lib, TANGO_GN_PROJ_STAT=on):
+            e.drop_plans()
+            outs[on] = e.unet_forward(x.cuda(), 500, enc.cuda(), mask.cuda()).cpu()
+            if on:
+                again = e.unet_forward(x.cuda(), 500, enc.cuda(), mask.cuda()).cpu()
+                assert torch.equal(again, outs[1])
+            labels = [r[0] for r in e.profile_unet(B2, 64)]
+        assert any(l.startswith("linear+gn(stat)") for l in labels) == (on == 1), labels[:12]
+    e.drop_plans()
+    sd = W.synth_state_dict(W.unet_param_shapes(O.UNET_CONFIG_LARGE, "unet."), 1234)
+    rows = [2, 13]
+    with torch.no_grad():
+        ref = O.unet_forward(sd, O.UNET_CONFIG_LARGE, x[rows], 500, enc[rows], mask[rows], prefix="unet.")
+    scale = ref.abs().max().item()
+    e0 = (outs[0][rows] - ref).abs().max().item() / scale
+    e1 = (outs[1][rows] - ref).abs().max().item() / scale
+    d = (outs[0] - outs[1]).abs().max().item() / scale
+    print("UNet forward %s B2=%d: GroupNorm kernel + proj_in GEMM vs oracle %.3e, statistics + stationary kernel vs oracle %.3e, apart %.3e" % (dtype, B2, e0, e1, d))
+    assert e0 <= tol and e1 <= tol and d <= tol
