@@ -12,7 +12,25 @@ NAMES = {
     0x122: "ablation: no GEGLU arithmetic", 0x124: "ablation: no LDS-DMA", 0x126: "ablation: no GEGLU arithmetic, no LDS-DMA",
     0x128: "ablation: no GEMM 2 MFMAs", 0x12e: "ablation: GEMM 1 skeleton only",
 }
-if len(sys.argv) > 1 and sys.argv[1] == "one":
+if len(sys.argv) > 1 and sys.argv[1] == "qkv":
+    # one timed batch of the activation-stationary QKV projection at the benchmarked size (PMC driver: tools/r6_pmc_stat_kernels.sh)
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from tango_amd import _lib
+    lib = _lib.load()
+    B, S, Ch = 64, 4096, 320
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(B * S, Ch, generator=g) * 1.2 + 0.3).cuda()
+    w = (torch.randn(3 * Ch, Ch, generator=g) / Ch ** 0.5).cuda()
+    ga, be = (1 + 0.2 * torch.randn(Ch, generator=g)).cuda(), (0.3 * torch.randn(Ch, generator=g)).cuda()
+    qk = torch.zeros(B * S, 2 * Ch, device="cuda")
+    vt = torch.zeros(B, Ch, S, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    ms = C.c_float(0.0)
+    rc = lib.tango_op_qkv_stat(1, p(x), p(w), p(ga), p(be), p(qk), p(vt), B, S, Ch, C.c_float(1e-5), int(sys.argv[2]) if len(sys.argv) > 2 else 0, 10, C.byref(ms), None)
+    assert rc == 0, lib.tango_last_error().decode()
+    print("qkv M=%d mode %s: %.3f ms" % (B * S, sys.argv[2] if len(sys.argv) > 2 else "0", ms.value))
+elif len(sys.argv) > 1 and sys.argv[1] == "one":
     import torch
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
     from tango_amd import _lib

@@ -12,6 +12,9 @@ Byte model (a LOWER bound: residual reads, bias / scale vectors and halo re-read
   xattn_block M C       x in, y out (K / V / weights are L2-resident)
   groupnorm C rows      read + write of batch2 x rows x C (the statistics pass is NOT in the floor: it is fusable in principle)
   layernorm C           read + write; rows = batch2 x (1024 for C = 640, 256 for C = 1280)
+  ff_fused M C          round 6: x in, y out, weights 12 C^2 once (the [M, 4C] GEGLU tensor does not exist)
+  qkv_stat M N K        round 6: as linear
+  groupnorm(stats)      round 6: one read of batch2 x rows x C
 """
 import argparse
 import re
@@ -22,7 +25,11 @@ PEAK_HBM = 8.0e12
 
 def op_bytes(name, b2):
     g = lambda k: int(re.search(r"\b%s=(\d+)" % k, name).group(1))  # noqa: E731
-    if name.startswith(("linear", "conv3x3")):
+    if name.startswith("ff_fused"):
+        return 2 * (2 * g("M") * g("C") + 12 * g("C") * g("C"))
+    if name.startswith("groupnorm(stats)"):
+        return 2 * b2 * g("rows") * g("C")
+    if name.startswith(("linear", "conv3x3", "qkv_stat")):
         M, N, K = g("M"), g("N"), g("K")
         out_n = N // 2 if (name.startswith("linear") and N in (2560, 5120, 10240)) else N
         if name.startswith("conv3x3up"):
@@ -75,7 +82,7 @@ def main():
                                                                              ms / fl if fl > 0 else float("nan"), ms - fl))
     out.append("# step: measured %.2f ms, sum of per-op floors %.2f ms (%.1f %% of measured); min bytes %.1f GB, %.1f TFLOP"
                % (tot_ms, tot_floor, 100 * tot_floor / tot_ms, sum(r[4] for r in rows) / 1e9, sum(r[3] for r in rows) / 1e3))
-    for fam in ("conv3x3", "linear", "attention", "xattn", "groupnorm", "layernorm"):
+    for fam in ("conv3x3", "linear", "ff_fused", "qkv_stat", "attention", "xattn", "groupnorm", "layernorm"):
         fr = [r for r in rows if r[0].startswith(fam)]
         if fr:
             m_, f_ = sum(r[2] for r in fr), sum(r[7] for r in fr)
