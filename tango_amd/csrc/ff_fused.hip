@@ -33,7 +33,7 @@ constexpr int FF_C = 320, FF_H = 1280, FF_BM = 128;
 constexpr int FF_KS = FF_C / 32;                 // k-steps of GEMM 1
 constexpr int FF_NCH = FF_H / 32;                // hidden chunks
 constexpr int FF_STAGE = 60 * 1024;
-constexpr int FF_PBUF = 8 * 1024;                // one parity of the P exchange: [rg 4][rt 2][l15 16][g 4][wn 2] x 8 B
+constexpr int FF_PBUF = 8 * 1024;                // one parity of the P exchange: [rg 4][rt 2][g 4][l15 16][wn 2] x 8 B
 constexpr int FF_LDS = 2 * FF_STAGE + 2 * FF_PBUF + 2 * FF_H * 4;
 }  // namespace
 
@@ -208,7 +208,10 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FFParams p) {
   const int foff = l15 * 64 + ((g ^ ((4 - (l15 >> 2)) & 3)) * 16);
   const int w1off = (wn * 2 * FF_KS) * 1024 + foff;                 // value tile of this wave; gate tile FF_KS groups further
   const int w2off = (40 + wn * 10) * 1024 + foff;
-  const int poff = ((rg * 2) * 64 + l15 * 4 + g) * 16;              // + rt * 1024
+  // slot order [g][l15] (not [l15][g]): the 16 lanes of a ds_write_b64 lane group (one g, l15 = 0..15) then write 16 distinct 16-byte slots of the
+  // 256-byte bank row, and ds_read_b128's lane groups read 16 distinct ones ([l15][g] was a 4-way conflict on every P store: 30 % of the kernel's
+  // LDS-active cycles were conflict replays, profiles/r6_final2_pmc_*)
+  const int poff = ((rg * 2) * 64 + g * 16 + l15) * 16;             // + rt * 1024
   // bias of this lane's 4 hidden units per chunk: packed index (2c + (g >> 1)) * 32 + gate * 16 + (g & 1) * 8 + wn * 4
   const int boff = (g >> 1) * 32 + (g & 1) * 8 + wn * 4;
 
