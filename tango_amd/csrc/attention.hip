@@ -95,8 +95,15 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // for any offset; the decision precedes the tile's exponentials and every P of the tile sees the same offset (the textbook order of
 // cdna_hip_programming.md T13).  Not bit-identical to the exact form: TANGO_ATTN_DEFER=0 selects that.
 static constexpr float ATTN_DEFER_LOG2 = 8.0f;
-template <typename T, int QB, bool MASKED, int NW, int MINW, bool PB = false, bool F8 = false, bool MSUM = false, bool X8 = false, bool DEFER = false>
+// KDMA (round 6, TANGO_ATTN_KDMA): the K tile arrives by LDS-DMA (global_load_lds, 8 rows x 128 B per instruction, the XOR swizzle applied on the SOURCE
+// side) instead of through VGPRs and ds_write_b128 -- the staging path was 21 % of the S = 4096 site in the ablation.  V^T still goes through registers
+// (its 8-byte column permutation is below the DMA's 16-byte granularity) -- unless the PRODUCER already stored the keys of every block of 32 in that
+// order (AttnParams::vt_perm, written by ff_fused.hip qkv_stat_kernel at the level-0 sites): VDMA fetches the V^T tile by LDS-DMA as well, no staging
+// registers, no ds_write in the loop.  Unmasked 16-bit sites.
+template <typename T, int QB, bool MASKED, int NW, int MINW, bool PB = false, bool F8 = false, bool MSUM = false, bool X8 = false, bool DEFER = false, bool KDMA = false, bool VDMA = false>
 __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p) {
+  static_assert(!VDMA || KDMA, "V^T by LDS-DMA rides on the K-by-DMA form (vt_perm layout: the producer stored the keys in fragment order)");
+  static_assert(!KDMA || (!MASKED && !F8 && !X8 && sizeof(T) == 2 && NW == 4), "K by LDS-DMA: unmasked 16-bit sites, four waves");
   static_assert(!DEFER || (!MASKED && !F8 && sizeof(T) == 2), "deferred rescale: unmasked 16-bit sites (the fp8 forms carry P at 2^8 already)");
   static_assert(!X8 || (F8 && MSUM && !MASKED), "MX P.V: the unmasked fp8 variant with matrix-pipe row sums");
   static_assert(!MSUM || sizeof(T) == 2, "matrix-pipe row sums: the P^T fragments of the 16-bit engines only");
@@ -174,6 +181,39 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
     voff[i] = X8 ? (unsigned)(id / VPPR) * (unsigned)(p.ldvt * (int64_t)sizeof(T)) + (id % VPPR) * 16
                  : (unsigned)row * (unsigned)(p.ldvt * (int64_t)sizeof(T)) + pc * 16;
   }
+  // KDMA: wave w fetches K rows (2 w + i) * 8 .. + 7, i = 0, 1; lane -> (row in the group = lane >> 3, LDS slot = lane & 7), source piece = slot ^ (row & 7)
+  unsigned kd_off[2] = {0u, 0u}, vd_off[2] = {0u, 0u};
+  if constexpr (KDMA) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (wave * 2 + i) * 8 + (lane >> 3);
+      kd_off[i] = (unsigned)row * (unsigned)(p.ldk * (int64_t)sizeof(T)) + (((lane & 7) ^ (row & 7)) * 16);
+      vd_off[i] = (unsigned)row * (unsigned)(p.ldvt * (int64_t)sizeof(T)) + (((lane & 7) ^ (row & 7)) * 16);   // row = head-dim index of V^T
+    }
+  }
+  auto dma_k = [&](int kv0, int st) {
+    if constexpr (KDMA) {
+      typedef const __attribute__((address_space(1))) void* gp_t;
+      typedef __attribute__((address_space(3))) void* lp_t;
+      const unsigned char* Kt = (const unsigned char*)Kp + (int64_t)kv0 * p.ldk * (int64_t)sizeof(T);
+      const unsigned lb = (unsigned)(uintptr_t)(lp_t)smem + (unsigned)st * STAGE + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 2048u;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        unsigned o = kd_off[i];
+        asm volatile("" : "+v"(o));
+        __builtin_amdgcn_global_load_lds((gp_t)(Kt + o), (lp_t)(uintptr_t)(lb + (unsigned)i * 1024u), 16, 0, 0);
+      }
+      if constexpr (VDMA) {
+        const unsigned char* Vt = (const unsigned char*)Vp + (int64_t)kv0 * (int64_t)sizeof(T);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          unsigned o = vd_off[i];
+          asm volatile("" : "+v"(o));
+          __builtin_amdgcn_global_load_lds((gp_t)(Vt + o), (lp_t)(uintptr_t)(lb + (unsigned)(KVT * LDSR) + (unsigned)i * 1024u), 16, 0, 0);
+        }
+      }
+    }
+  };
   auto load_tile = [&](int kv0) {
     const unsigned char* Kt = (const unsigned char*)Kp + (int64_t)kv0 * p.ldk * (int64_t)sizeof(T);
     const unsigned char* Vt = (const unsigned char*)Vp + (int64_t)kv0 * (int64_t)sizeof(T);
@@ -188,8 +228,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
         if (kv0 + pc * EPV < p.ldvt) vv = *(const u32x4*)(Vt + voff[i]);
         kreg[i] = kk; vreg[i] = vv;
       } else {
-        kreg[i] = *(const u32x4*)(Kt + koff[i]);
-        vreg[i] = *(const u32x4*)(Vt + voff[i]);
+        if constexpr (!KDMA) kreg[i] = *(const u32x4*)(Kt + koff[i]);
+        if constexpr (!VDMA) vreg[i] = *(const u32x4*)(Vt + voff[i]);
       }
     }
   };
@@ -216,15 +256,17 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
         *(unsigned*)(vr + (((4 * j + gg0) ^ sw) * 8) + hi * 4) = pack_fp8x4(f[0], f[1], f[2], f[3]);
         *(unsigned*)(vr + (((4 * j + gg0 + 1) ^ sw) * 8) + hi * 4) = pack_fp8x4(f[4], f[5], f[6], f[7]);
       } else if (HALF) {
-        *(u32x4*)(Ks + row * LDSR + ((pc ^ (row & 7)) * 16)) = kreg[i];
+        if constexpr (!KDMA) *(u32x4*)(Ks + row * LDSR + ((pc ^ (row & 7)) * 16)) = kreg[i];
         // V^T: piece pc holds kv = 8pc..8pc+7 of this 64-tile: 32-block j = pc>>2, c = (pc&3)*8 + e.
         // column c = 16*hi + 4*gg + r is stored at c' = 8*gg + 4*hi + r (so [hi=0 | hi=1] of one gg are adjacent)
+        if constexpr (!VDMA) {
         const int j = pc >> 2, hi = (pc >> 1) & 1, gg0 = (pc & 1) * 2;
         const u32x2 lo = u32x2{vreg[i][0], vreg[i][1]}, hh = u32x2{vreg[i][2], vreg[i][3]};
         // bytes within the row: 64*j + 2*(8*gg + 4*hi) ; 16-byte piece index = 4*j + gg, half = hi
         unsigned char* vr = Vs + row * LDSR;
         *(u32x2*)(vr + (((4 * j + gg0) ^ (row & 7)) * 16) + hi * 8) = lo;
         *(u32x2*)(vr + (((4 * j + gg0 + 1) ^ (row & 7)) * 16) + hi * 8) = hh;
+        }
       } else {
         *(u32x4*)(Ks + row * LDSR + pc * 16) = kreg[i];
         *(u32x4*)(Vs + row * LDSR + pc * 16) = vreg[i];
@@ -274,6 +316,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
     load_part(0, 0); store_part(0, 0);
     load_part(0, 1); store_part(0, 1);
   } else {
+    dma_k(0, 0);
     load_tile(0);
     store_tile(0);
   }
@@ -283,7 +326,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
     const int kv0 = t * KVT;
     const bool more = t + 1 < ntile;
     if constexpr (X8) { if (more) load_part(kv0 + KVT, 0); }
-    else { if (more) load_tile(kv0 + KVT); }
+    else { if (more) { dma_k(kv0 + KVT, (t + 1) & 1); load_tile(kv0 + KVT); } }
     const unsigned char* Ks = smem + (t & 1) * STAGE;
     const unsigned char* Vs = Ks + KVT * LDSR;
 
@@ -503,12 +546,18 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const AttnParams p)
   }
 }
 
+bool attention_vt_perm_ok(int dtype, const AttnParams& p) {
+  return dtype != DT_F32 && !p.bias && !p.pos_bias && p.Skv % 64 == 0 && p.Sq > 512 && p.fp8_pv == 0 && p.ldvt % 8 == 0;
+}
+
 template <typename T>
 static int attn_launch(const AttnParams& p, hipStream_t s) {
   if ((p.ldq * (int64_t)sizeof(T)) % 16 || (p.ldk * (int64_t)sizeof(T)) % 16 || (p.ldvt * (int64_t)sizeof(T)) % 16 ||
       (p.ldo * (int64_t)sizeof(T)) % 8)
     TANGO_FAIL("attention: ld alignment");
   const bool masked = p.bias != nullptr || (p.Skv % 64) != 0;
+  // a permuted V^T is only understood by the LDS-DMA form of the long unmasked 16-bit sites: never read it with another kernel
+  if (p.vt_perm && !attention_vt_perm_ok(TypeTag<T>::dt, p)) TANGO_FAIL("attention: vt_perm needs an unmasked 16-bit site with Sq > 512, Skv % 64 == 0, no fp8 P.V");
   if (p.fp8_pv && sizeof(T) != 2) TANGO_FAIL("attention: fp8 P.V needs a 16-bit engine (Q.K^T stays in the engine dtype)");
   //  never fall back silently: a config-5 run must not measure the 16-bit kernel under the fp8 label
   if (p.fp8_pv && (masked || p.pos_bias)) TANGO_FAIL("attention: fp8 P.V is implemented for unmasked sites with Skv % 64 == 0 only");
@@ -544,9 +593,11 @@ static int attn_launch(const AttnParams& p, hipStream_t s) {
     dim3 grid((unsigned)((p.Sq + 64 * QB - 1) / (64 * QB)), (unsigned)p.heads, (unsigned)p.B);
     if (masked) hipLaunchKernelGGL((attn_kernel<T, QB, true, 4, 3>), grid, dim3(256), 0, s, p);
     else if constexpr (sizeof(T) == 2) {
-      if (p.fp8_pv && tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true, true>), grid, dim3(256), 0, s, p);
+      if (p.vt_perm) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, true, false, false, true, true>), grid, dim3(256), 0, s, p);
+      else if (p.fp8_pv && tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true, true>), grid, dim3(256), 0, s, p);
       else if (p.fp8_pv) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, true>), grid, dim3(256), 0, s, p);
       else if (tuning().attn_msum && tuning().attn_defer) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, true, false, true>), grid, dim3(256), 0, s, p);
+      else if (tuning().attn_msum && tuning().attn_kdma) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, true, false, false, true>), grid, dim3(256), 0, s, p);
       else if (tuning().attn_msum) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, true>), grid, dim3(256), 0, s, p);
       else if (tuning().attn_defer) hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3, false, false, false, false, true>), grid, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<T, QB, false, 4, 3>), grid, dim3(256), 0, s, p);

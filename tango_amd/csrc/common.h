@@ -275,6 +275,7 @@ struct QKVParams {
   const float* b = nullptr;                      // folded bias b' [N] (may be null)
   void* out = nullptr; int64_t ldo = 0;
   void* vt = nullptr; int64_t vt_ld = 0; int vt_S = 0;
+  int vt_perm = 0;                             // 1: tokens permuted inside every block of 32 (AttnParams::vt_perm)
   int M = 0, N = 0, K = 0, n_rm = 0;
   int ln = 1; float eps = 1e-5f;               // ln: 0 = no normalisation, 1 = LayerNorm over K inside the kernel, 2 = GroupNorm with given statistics:
   const float* gstats = nullptr;               //   mean / rstd per (sample, group) [M / rows_ps][groups][2] (norm.hip launch_gn_stats_mr), w / b folded with its gamma / beta
@@ -326,9 +327,12 @@ struct AttnParams {
   const float* pos_bias = nullptr; // [heads][Sq][Skv] additive, shared by the batch (T5 relative position bias) or null
   int B, heads, Sq, Skv;
   float scale;
+  int vt_perm = 0;                // 1: vt's keys are stored permuted inside every block of 32 (position 8 gg + 4 hi + r holds key 16 hi + 4 gg + r: the order the P^T
+                                  // fragments present them), written so by qkv_stat_kernel; the kernel then fetches BOTH tiles by LDS-DMA (attention.hip KDMA + VDMA)
   int fp8_pv = 0;                 // 16-bit engines, unmasked (self-attention) sites: P and V as e4m3 on the fp8 MFMA (attention.hip); 2 = the MX instruction (128 keys per MFMA, unit scales)
 };
 int launch_attention(int dtype, const AttnParams& p, hipStream_t s);
+bool attention_vt_perm_ok(int dtype, const AttnParams& p);   // this site can read a vt_perm V^T (the producer may then write one)
 
 // ---- fused cross-attention block (xattn.hip): y = x + to_out(softmax(to_q(LayerNorm(x)) K^T / 8 + bias) V) + b_out ----
 struct XAttnParams {

@@ -242,11 +242,11 @@ struct Builder {
   }
 
   // norm1 -> [to_q | to_k | to_v^T] of the level-0 self-attention on the activation-stationary kernel (round 6; ff_fused.hip qkv_stat_kernel)
-  bool qkv_stat(const TView& x, int64_t rows, const XfW& w, const TView& qk, void* vt, int HW) {
+  bool qkv_stat(const TView& x, int64_t rows, const XfW& w, const TView& qk, void* vt, int HW, int vt_perm) {
     if (!tuning().qkv_stat || !w.qkv.Wln || rows < tuning().qkv_min_rows) return false;
     QKVParams q;
     q.x = x.p; q.ldx = x.ld; q.w = w.qkv.Wln; q.ldw = w.qkv.Kp; q.b = w.qkv.bln; q.out = qk.p; q.ldo = qk.ld; q.vt = vt; q.vt_ld = HW; q.vt_S = HW;
-    q.M = (int)rows; q.N = 3 * w.C; q.K = w.C; q.n_rm = 2 * w.C; q.ln = 1; q.eps = w.ln1.eps;
+    q.M = (int)rows; q.N = 3 * w.C; q.K = w.C; q.n_rm = 2 * w.C; q.ln = 1; q.eps = w.ln1.eps; q.vt_perm = vt_perm;
     if (!qkv_stat_ok(dt, q)) return false;
     const int d = dt;
     char buf[96];
@@ -295,8 +295,9 @@ struct Builder {
   }
 
   void attention(const TView& q, const TView& k, const void* vt, int64_t ldvt, const TView& o, const float* bias, int B, int heads,
-                 int Sq, int Skv, float scale = 0.125f, const float* pos_bias = nullptr, int fp8_pv = 0) {
+                 int Sq, int Skv, float scale = 0.125f, const float* pos_bias = nullptr, int fp8_pv = 0, int vt_perm = 0) {
     AttnParams p;
+    p.vt_perm = vt_perm;
     p.fp8_pv = fp8_pv;                // 0: engine dtype, 1: non-scaled fp8 MFMA, 2: MX fp8 (128 keys per MFMA)
     p.q = q.p; p.ldq = q.ld; p.k = k.p; p.ldk = k.ld; p.vt = vt; p.ldvt = ldvt; p.o = o.p; p.ldo = o.ld;
     p.bias = bias; p.pos_bias = pos_bias; p.B = B; p.heads = heads; p.Sq = Sq; p.Skv = Skv; p.scale = scale;
@@ -394,15 +395,25 @@ struct Builder {
     TView qkv = alloc(rows_p, 2 * C);               // [q | k]; v goes transposed into vt [B][C][HW]
     void* vt = A.alloc((size_t)rows_p * C * esz);
     GOpt nb; nb.use_bias = false;
-    if (!qkv_stat(h, rows_p, w, qkv, vt, HW)) {
+    const int attn_fp8 = (E.cfg.unet_attn_fp8 != 0 && dt != DT_F32 && HW % 64 == 0) ? ((E.cfg.unet_attn_fp8 == 2 && HW % 128 == 0) ? 2 : 1) : 0;
+    // round 6: where the projection runs on the activation-stationary kernel AND the attention site can fetch by LDS-DMA, v^T is written with its
+    // keys in the attention kernel's fragment order (AttnParams::vt_perm): producer and consumer agree here, in one place
+    int vperm = 0;
+    {
+      AttnParams ap;
+      ap.q = nullptr; ap.k = nullptr; ap.vt = nullptr; ap.o = nullptr; ap.ldq = ap.ldk = ap.ldo = 0; ap.ldvt = HW;
+      ap.bias = nullptr; ap.B = Bp; ap.heads = w.heads; ap.Sq = HW; ap.Skv = HW; ap.scale = 0.125f; ap.fp8_pv = attn_fp8;
+      vperm = tuning().attn_vdma && attention_vt_perm_ok(dt, ap) ? 1 : 0;
+    }
+    if (!qkv_stat(h, rows_p, w, qkv, vt, HW, vperm)) {
+      vperm = 0;
       GOpt o = nb; o.ln = &w.ln1; o.vt = vt; o.vt_n0 = 2 * C; o.vt_S = HW; o.vt_ld = HW; linear(h, rows_p, w.qkv, qkv, o);
     }
     TView a = alloc(rows_p, C);
     // self-attention; `unet_attn_fp8` (BASELINE config 5): P.V on the fp8 MFMA at the sites that dominate the attention time
     // (unmasked, Skv a multiple of 64); cross-attention (64 text tokens, masked) stays in the engine dtype
     // (unet_attn_fp8 == 2, round 6: the MX instruction, 128 keys per MFMA, where the sequence is a multiple of 128)
-    attention(slice(qkv, 0, C, esz), slice(qkv, C, C, esz), vt, HW, a, nullptr, Bp, w.heads, HW, HW, 0.125f, nullptr,
-              (E.cfg.unet_attn_fp8 != 0 && dt != DT_F32 && HW % 64 == 0) ? ((E.cfg.unet_attn_fp8 == 2 && HW % 128 == 0) ? 2 : 1) : 0);
+    attention(slice(qkv, 0, C, esz), slice(qkv, C, C, esz), vt, HW, a, nullptr, Bp, w.heads, HW, HW, 0.125f, nullptr, attn_fp8, vperm);
     TView h1 = alloc(rows, C);
     TView h2 = h;                       // h is dead after h1 was produced
     const int Lp8 = (L + 7) / 8 * 8;

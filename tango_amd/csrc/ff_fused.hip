@@ -482,7 +482,7 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(const FFParams p) {
 namespace {
 constexpr int QS_BM = 256, QS_CH = 64, QS_STAGE = 40 * 1024, QS_NST = 3;
 constexpr int QS_MAXN = 1024;
-constexpr int QS_WSTG = 64 * 48;                 // per-wave staging slice: 16 rows x (128 B + 16) for row-major chunks, 64 channels x (32 B + 16) for transposed ones
+constexpr int QS_WSTG = 64 * 64;                 // per-wave staging slice: 16 rows x (128 B + 16) for row-major chunks, 64 channels x (32 B + 16) for transposed ones
 constexpr int QS_LDS = QS_NST * QS_STAGE + QS_MAXN * 4 + 8 * QS_WSTG;
 }  // namespace
 
@@ -675,6 +675,29 @@ __global__ __launch_bounds__(512) void qkv_stat_kernel(const QKVParams p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) sink += acc[t][0][0] + acc[t][1][3];
       if (sink == 12345.678f) O[0] = from_f<T>(sink);
+    } else if (STG && VT && p.vt_perm) {
+      // transposed chunk in the attention kernel's fragment order (AttnParams::vt_perm): inside the wave's block of 32 tokens, position 8 g + 4 rt + r
+      // holds token 16 rt + 4 g + r.  Both passes through the staging slice ([channel 64][64 B], 16-byte pieces XOR-swizzled by (channel >> 2) & 3:
+      // conflict-free for the 8-byte writes and the 16-byte reads), then 4 sixteen-byte stores per lane: 64-byte runs per channel
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const f32x4 v = acc[t][rt];
+          T o4[4] = {from_f<T>(v[0]), from_f<T>(v[1]), from_f<T>(v[2]), from_f<T>(v[3])};
+          u32x2 ow;
+          __builtin_memcpy(&ow, o4, 8);
+          const int ch = t * 16 + l15;
+          *(u32x2*)(stg + ch * 64 + ((g ^ ((ch >> 2) & 3)) * 16) + rt * 8) = ow;
+        }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = lane + it * 64, ch = idx >> 2, pi = idx & 3;
+        const u32x4 o = *(const u32x4*)(stg + ch * 64 + ((pi ^ ((ch >> 2) & 3)) * 16));
+        *(u32x4*)((T*)p.vt + ((int64_t)bb * (p.N - p.n_rm) + (c * QS_CH - p.n_rm + ch)) * p.vt_ld + s0 + wave * 32 + pi * 8) = o;
+      }
+      __builtin_amdgcn_wave_barrier();
     } else if constexpr (STG) {
       // two passes of 16 x-rows: the wave's 16 x 64 block (row-major chunks) or 64 x 16 block (transposed chunks: 64 channels x 16 tokens)
       // through its staging slice, then 16-byte pieces -- 2 stores per lane and pass, whole 128-byte rows (32-byte token runs for v^T)

@@ -140,3 +140,36 @@ def test_unet_forward_with_groupnorm_proj_in_on_the_stationary_kernel(lib, dtype
     d = (outs[0] - outs[1]).abs().max().item() / scale
     print("UNet forward %s B2=%d: GroupNorm kernel + proj_in GEMM vs oracle %.3e, statistics + stationary kernel vs oracle %.3e, apart %.3e" % (dtype, B2, e0, e1, d))
     assert e0 <= tol and e1 <= tol and d <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp16", 4e-3), ("bf16", 4e-2)])
+def test_unet_forward_with_kv_tiles_by_lds_dma(lib, dtype, tol):
+    """level-0 self-attention with the K tile, and -- v^T written in fragment order by qkv_stat_kernel (AttnParams::vt_perm) -- the V^T tile fetched by
+    LDS-DMA (attention.hip KDMA / VDMA; reference op attention_processor.py:495-540): same arithmetic as the register-staged kernel, so the three forms
+    must agree BITWISE through a whole UNet forward; and against the oracle"""
+    from oracle import tango_oracle as O
+    from tango_amd import weights as W
+    from tango_amd.engine import UNET_CONFIG_LARGE, Engine
+    B2 = 16
+    g = torch.Generator().manual_seed(37)
+    x = torch.randn(B2, 8, 256, 16, generator=g)
+    enc = torch.randn(B2, 64, 1024, generator=g)
+    mask = torch.ones(B2, 64, dtype=torch.bool)
+    mask[: B2 // 2, 1:] = False
+    e = Engine(unet=UNET_CONFIG_LARGE, dtype=dtype)
+    e.load_synthetic(1234)
+    outs = {}
+    for kd, vd in ((0, 0), (1, 0), (1, 1)):
+        with tuning(lib, TANGO_ATTN_KDMA=kd, TANGO_ATTN_VDMA=vd):
+            e.drop_plans()
+            outs[(kd, vd)] = e.unet_forward(x.cuda(), 500, enc.cuda(), mask.cuda()).cpu()
+    e.drop_plans()
+    assert torch.equal(outs[(0, 0)], outs[(1, 0)]), "K by LDS-DMA: %d elements differ" % (outs[(0, 0)] != outs[(1, 0)]).sum().item()
+    assert torch.equal(outs[(0, 0)], outs[(1, 1)]), "K and V^T by LDS-DMA: %d elements differ" % (outs[(0, 0)] != outs[(1, 1)]).sum().item()
+    sd = W.synth_state_dict(W.unet_param_shapes(O.UNET_CONFIG_LARGE, "unet."), 1234)
+    rows = [3, 12]
+    with torch.no_grad():
+        ref = O.unet_forward(sd, O.UNET_CONFIG_LARGE, x[rows], 500, enc[rows], mask[rows], prefix="unet.")
+    err = (outs[(1, 1)][rows] - ref).abs().max().item() / ref.abs().max().item()
+    print("UNet forward %s B2=%d with K / V^T tiles by LDS-DMA vs oracle %.3e (bit-identical to the register-staged kernel)" % (dtype, B2, err))
+    assert err <= tol

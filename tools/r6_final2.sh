@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-6 end-of-round evidence on the final tree, one gpurun call: smoke, the default bench line, rocprofv3 kernel stats + HBM-side PMC passes
 # (tools/final_profiles.sh), per-op tables B = 32 / 8 / 1 with the per-op roofline, VAE / vocoder per-op tables, PMC of the activation-stationary kernels.
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/final2; mkdir -p $OUT; cd $R
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/${FINAL_DIR:-final2}; mkdir -p $OUT; cd $R
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 600 $OUT/bench.json
 for b in 32 8 1; do python tools/profile_unet_ops.py --batch $b --out $OUT/unet_step_per_op_fp16_b$b.txt > /dev/null 2>&1; done
