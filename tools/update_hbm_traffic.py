@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Turn the totals of tools/final_profiles.sh (gpurun_out/final*/pmc_totals.txt: FETCH_SIZE / WRITE_SIZE sums over N = 2 and N = 6 denoise steps) into
 the evidence file profiles/<name> and a record of profiles/hbm_traffic.json keyed to the CURRENT kernel sources (bench.kernel_source_sha16).
-usage: python tools/update_hbm_traffic.py gpurun_out/final2/pmc_totals.txt profiles/r6_final2_pmc_hbm_traffic_unet_step.txt"""
+usage: python tools/update_hbm_traffic.py gpurun_out/final2/pmc_totals.txt profiles/r6_final2_pmc_hbm_traffic_unet_step.txt [src_sha16]"""
 import json
 import os
 import re
@@ -20,7 +20,7 @@ for l in lines:
         tot[(int(m.group(1)), m.group(2))] = float(m.group(3))
 fetch = (tot[(6, "FETCH_SIZE")] - tot[(2, "FETCH_SIZE")]) / 4 * 1024
 write = (tot[(6, "WRITE_SIZE")] - tot[(2, "WRITE_SIZE")]) / 4 * 1024
-sha = bench.kernel_source_sha16()
+sha = sys.argv[3] if len(sys.argv) > 3 else bench.kernel_source_sha16()   # (third argument: the hash the totals were MEASURED on, when it is not the working tree)
 with open(os.path.join(ROOT, dst), "w") as o:
     o.write("# HBM-side bytes of one denoise-step launch (B=32, fp16, hipGraph replay) on kernel sources %s\n" % sha)
     o.write("# separate rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py --batch 32 --denoise-steps N --steps 1 --warmup 0 --no-cpu-baseline` (tools/final_profiles.sh),\n")
