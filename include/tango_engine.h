@@ -245,6 +245,10 @@ int tango_op_linear_ln(int dtype, const float* x, const float* w, const float* b
    [B][C][S]; gamma == NULL skips the LayerNorm */
 int tango_op_linear_qkv(int dtype, const float* x, const float* w, const float* gamma, const float* beta, float* out_qk,
                         float* out_vt, int B, int S, int C, int K, float eps, void* stream);
+/* the same with the tokens of every block of 32 of out_vt in the attention kernel's fragment order when vt_perm = 1 (position 8 g + 4 hi + r
+   holds token 16 hi + 4 g + r: what tango_op_attention's LDS-DMA form reads; 16-bit engines, S % 32 == 0) */
+int tango_op_linear_qkv_perm(int dtype, const float* x, const float* w, const float* gamma, const float* beta, float* out_qk,
+                             float* out_vt, int B, int S, int C, int K, float eps, int vt_perm, void* stream);
 /* the level-0 feed-forward of BasicTransformerBlock with its LayerNorm and residual (reference: diffusers attention.py:326-335 norm3 -> ff ->
    + hidden_states, :338-387 FeedForward, :412-433 GEGLU): out [M, C] = x + W2 GEGLU(W1 LayerNorm(x) + b1) + b2, w1 [2H, C] in the reference
    row order (value rows, then gate rows), w2 [C, H].  mode 0 = ONE launch (csrc/ff_fused.hip; C = 320, H = 1280, M % 128 == 0, 16-bit),
@@ -266,7 +270,9 @@ int tango_op_layernorm(int dtype, const float* x, const float* gamma, const floa
 int tango_op_attention(int dtype, const float* q, const float* k, const float* v, const float* bias, float* out, int B, int heads,
                        int Sq, int Skv, float scale, void* stream);
 /* as tango_op_attention; flags bit 0: P.V on the fp8 MFMA (16-bit dtypes, no bias, Skv % 64 == 0); bit 1 (with bit 0): on the MX
- * instruction, 128 keys per MFMA (Skv % 128 == 0) */
+ * instruction, 128 keys per MFMA (Skv % 128 == 0); bit 2: the rows of v are given in the kernel's fragment order inside every block of
+ * 32 keys (row 8 g + 4 hi + r of a block holds key 16 hi + 4 g + r) -- the op's V^T is then the permuted one the engine's producers write
+ * and both tiles travel by LDS-DMA (unmasked 16-bit problems with Sq > 512, Skv % 64 == 0; refused otherwise) */
 int tango_op_attention_ex(int dtype, const float* q, const float* k, const float* v, const float* bias, float* out, int B, int heads,
                           int Sq, int Skv, float scale, int flags, void* stream);
 /* fused cross-attention block of BasicTransformerBlock (diffusers attention.py:312-323: attn2(norm2(x), text, mask) + x) as the engine

@@ -104,7 +104,7 @@ SYMBOLS = [
     "tango_engine_finalize_weights", "tango_engine_denoise", "tango_engine_unet_forward", "tango_engine_unet_forward_music",
     "tango_engine_vae_decode", "tango_engine_vae_encode", "tango_engine_vocode", "tango_engine_vocoder_samples", "tango_engine_encode_text",
     "tango_engine_mel_frames", "tango_engine_mel_spectrogram",
-    "tango_engine_last_denoise_ms", "tango_engine_last_step_gflop", "tango_engine_profile_unet", "tango_engine_profile_vae", "tango_engine_profile_vocoder", "tango_engine_set_plan_budget", "tango_engine_plan_stats", "tango_engine_drop_plans", "tango_op_conv2d", "tango_op_linear", "tango_op_linear_ln", "tango_op_ff_fused", "tango_op_qkv_stat", "tango_op_linear_qkv", "tango_op_conv1d",
+    "tango_engine_last_denoise_ms", "tango_engine_last_step_gflop", "tango_engine_profile_unet", "tango_engine_profile_vae", "tango_engine_profile_vocoder", "tango_engine_set_plan_budget", "tango_engine_plan_stats", "tango_engine_drop_plans", "tango_op_conv2d", "tango_op_linear", "tango_op_linear_ln", "tango_op_ff_fused", "tango_op_qkv_stat", "tango_op_linear_qkv", "tango_op_linear_qkv_perm", "tango_op_conv1d",
     "tango_op_conv_transpose1d", "tango_op_groupnorm", "tango_op_layernorm", "tango_op_attention", "tango_op_attention_ex", "tango_op_xattn_block",
     "tango_op_sched_step", "tango_op_philox_normal",
 ]
@@ -160,6 +160,7 @@ def load():
     lib.tango_op_ff_fused.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, ci, ci, vp, vp]
     lib.tango_op_qkv_stat.argtypes = [ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, ci, ci, vp, vp]
     lib.tango_op_linear_qkv.argtypes = [ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp]
+    lib.tango_op_linear_qkv_perm.argtypes = [ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, ci, vp]
     lib.tango_op_conv1d.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, ci, cf, vp]
     lib.tango_op_conv_transpose1d.argtypes = [ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp]
     lib.tango_op_groupnorm.argtypes = [ci, vp, vp, vp, vp, ci, ci, ci, ci, cf, ci, vp]

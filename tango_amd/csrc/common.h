@@ -194,6 +194,7 @@ struct GemmParams {
   void* vt = nullptr;
   int vt_n0 = 0, vt_S = 1;
   int64_t vt_ld = 0;
+  int vt_perm = 0;           // 1: the tokens of every block of 32 go out in the attention kernel's fragment order (vt_perm_pos; AttnParams::vt_perm); vt_S % 32 == 0
   // Per-sample row vector for a leading range of rows (round 4; gemm_wide_device.h wide_epilogue only -- the 256 x 320 and 256 x 160
   // kernels): rows m < rowvec_rows additionally get rowvec[(m / rowvec_per) * N + n] (fp32) and are written to out_lo (row stride
   // ldo_lo) instead of `out`.  The single-key cross-attention rows of a CFG batch (engine.hip transformer()): attn1's to_out + residual
@@ -332,6 +333,8 @@ struct AttnParams {
   int fp8_pv = 0;                 // 16-bit engines, unmasked (self-attention) sites: P and V as e4m3 on the fp8 MFMA (attention.hip); 2 = the MX instruction (128 keys per MFMA, unit scales)
 };
 int launch_attention(int dtype, const AttnParams& p, hipStream_t s);
+// position of token s of a sequence in a vt_perm V^T: inside its block of 32, key 16 hi + 4 g + r sits at 8 g + 4 hi + r
+__host__ __device__ inline int vt_perm_pos(int s) { return (s & ~31) | ((s & 12) << 1) | ((s & 16) >> 2) | (s & 3); }
 bool attention_vt_perm_ok(int dtype, const AttnParams& p);   // this site can read a vt_perm V^T (the producer may then write one)
 
 // ---- fused cross-attention block (xattn.hip): y = x + to_out(softmax(to_q(LayerNorm(x)) K^T / 8 + bias) V) + b_out ----

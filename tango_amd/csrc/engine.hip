@@ -37,6 +37,7 @@ struct GOpt {
   void* vt = nullptr;
   int vt_n0 = 0, vt_S = 1;
   int64_t vt_ld = 0;
+  int vt_perm = 0;               // the transposed columns in the attention kernel's fragment order (GemmParams::vt_perm)
   const WNorm* ln = nullptr;     // apply LayerNorm(ln) to the input rows first (folded when the streaming kernel applies)
   int glu_tanh = 0;              // EPI_GEGLU gate: tanh GELU (T5 gated-gelu) instead of exact-erf GELU
   int pad = 1;                   // conv3x3: top / left zero padding (0 = the VAE Downsample's asymmetric (0,1,0,1) pad)
@@ -107,7 +108,7 @@ struct Builder {
     if (o.residual) { p.R = o.residual->p; p.ldr = o.residual->ld; }
     p.a_act = o.a_act; p.a_slope = o.a_slope; p.e_act = o.e_act; p.e_slope = o.e_slope; p.epi = o.epi; p.glu_tanh = o.glu_tanh;
     p.bias2 = o.bias2; p.bias2_stride = o.bias2_stride; p.step_ptr = o.bias2 ? E.d_step : nullptr;
-    if (o.vt) { p.epi = EPI_VT; p.vt = o.vt; p.vt_n0 = o.vt_n0; p.vt_S = o.vt_S; p.vt_ld = o.vt_ld; }
+    if (o.vt) { p.epi = EPI_VT; p.vt = o.vt; p.vt_n0 = o.vt_n0; p.vt_S = o.vt_S; p.vt_ld = o.vt_ld; p.vt_perm = o.vt_perm; }
     if (o.ln) {
       GemmParams q = p;
       q.W = w.Wln; q.bias = w.bln; q.ln_fold = 1; q.ln_eps = o.ln->eps; q.wsum = w.wsum;
@@ -406,8 +407,10 @@ struct Builder {
       vperm = tuning().attn_vdma && attention_vt_perm_ok(dt, ap) ? 1 : 0;
     }
     if (!qkv_stat(h, rows_p, w, qkv, vt, HW, vperm)) {
-      vperm = 0;
-      GOpt o = nb; o.ln = &w.ln1; o.vt = vt; o.vt_n0 = 2 * C; o.vt_S = HW; o.vt_ld = HW; linear(h, rows_p, w.qkv, qkv, o);
+      // GEMM-route producers (levels 1-2; level 0 below the activation-stationary kernel's row threshold): every EPI_VT epilogue can write the
+      // permuted order as well (TANGO_ATTN_VDMA=2, the default; 1 = only qkv_stat_kernel does)
+      if (tuning().attn_vdma < 2) vperm = 0;
+      GOpt o = nb; o.ln = &w.ln1; o.vt = vt; o.vt_n0 = 2 * C; o.vt_S = HW; o.vt_ld = HW; o.vt_perm = vperm; linear(h, rows_p, w.qkv, qkv, o);
     }
     TView a = alloc(rows_p, C);
     // self-attention; `unet_attn_fp8` (BASELINE config 5): P.V on the fp8 MFMA at the sites that dominate the attention time

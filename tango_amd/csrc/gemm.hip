@@ -414,6 +414,7 @@ bool gemm_rowvec_ok(int dtype, const GemmParams& p) {
 int launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
   if (p.rowvec && !gemm_rowvec_ok(dtype, p)) TANGO_FAIL("gemm: rowvec is only implemented by the 256 x 320 / 256 x 160 GEMM epilogues");
   const int route = gemm_route(dtype, p);
+  if (p.epi == EPI_VT && p.vt_perm && (p.vt_S % 32 != 0 || dtype == DT_F32)) TANGO_FAIL("gemm: vt_perm permutes whole blocks of 32 tokens of a 16-bit V^T (vt_S % 32 == 0)");
   if (p.wb_rows && route != ROUTE_WIDE && route != ROUTE_DUO) TANGO_FAIL("gemm: per-sample weights are implemented by the 256 x 320 / 256 x 160 GEMMs only");
   if (p.glu_tanh && dtype != DT_F32 && route != ROUTE_WIDE && route != ROUTE_DUO)
     TANGO_FAIL("gemm: the tanh-GELU gate (T5 gated-gelu) is implemented by the fp32 kernels and the 256 x 320 / 256 x 160 GEMMs only");

@@ -99,7 +99,8 @@ __device__ __forceinline__ void gemm_epilogue_body(const GemmParams& p, f32x4 (&
     if (m < p.M) {
       if (epi == EPI_VT) {
         const int bb = m / p.vt_S;
-        vtrow[b] = (int64_t)bb * (p.N - p.vt_n0) * p.vt_ld + (m - bb * p.vt_S);
+        const int sq = m - bb * p.vt_S;
+        vtrow[b] = (int64_t)bb * (p.N - p.vt_n0) * p.vt_ld + (p.vt_perm ? vt_perm_pos(sq) : sq);
       }
       if (MODE == MODE_CONV1D) {
         const int bb = m / p.rows_pb, q = m - bb * p.rows_pb;

@@ -146,6 +146,11 @@ __device__ __forceinline__ void wide_epilogue_vt(const GemmParams& p, f32x4 (&ac
   __builtin_amdgcn_wave_barrier();
   const int bb = m_base / p.vt_S, s0 = m_base - bb * p.vt_S;
   T* const vbase = (T*)p.vt + ((int64_t)bb * (p.N - p.vt_n0) + (n_base - p.vt_n0)) * p.vt_ld + s0;
+  // token b * 16 + l15 of the wave's 64 rows -> its position in the staged column (vt_perm: the attention kernel's fragment order inside every
+  // block of 32 -- s0 is a multiple of 64, so the blocks of the tile are the blocks of the sequence)
+  int tpos[TM];
+#pragma unroll
+  for (int b = 0; b < TM; ++b) tpos[b] = p.vt_perm ? vt_perm_pos(b * 16 + l15) : b * 16 + l15;
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
 #pragma unroll
@@ -155,7 +160,7 @@ __device__ __forceinline__ void wide_epilogue_vt(const GemmParams& p, f32x4 (&ac
       for (int b = 0; b < TM; ++b) {
         const f32x4 v = wide_col_value<LN>(acc[a][b], mean[b], rstd[b], p.alpha, cst + a * 16 + g4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) *(T*)(stage + (al * 16 + g4 + r) * CPITCH + (b * 16 + l15) * 2) = from_f<T>(v[r]);
+        for (int r = 0; r < 4; ++r) *(T*)(stage + (al * 16 + g4 + r) * CPITCH + tpos[b] * 2) = from_f<T>(v[r]);
       }
     }
     __builtin_amdgcn_wave_barrier();

@@ -264,7 +264,8 @@ __global__ __launch_bounds__(512, 2) void lin_stream_kernel(const GemmParams p) 
       if (epi == EPI_VT) {
         const int mm = (int)orow[tm];
         const int bb = mm / p.vt_S;
-        vtrow[tm] = (int64_t)bb * (p.N - p.vt_n0) * p.vt_ld + (mm - bb * p.vt_S);
+        const int sq = mm - bb * p.vt_S;
+        vtrow[tm] = (int64_t)bb * (p.N - p.vt_n0) * p.vt_ld + (p.vt_perm ? vt_perm_pos(sq) : sq);
       }
     }
     const bool panel_vt = (epi == EPI_VT) && n0e >= p.vt_n0;

@@ -240,6 +240,12 @@ const char* tango_debug_linear_route(int dt, int M, int N, int K, int geglu, int
 
 int tango_op_linear_qkv(int dt, const float* x, const float* w, const float* gamma, const float* beta, float* out_qk, float* out_vt,
                         int B, int S, int C, int K, float eps, void* stream) {
+  return tango_op_linear_qkv_perm(dt, x, w, gamma, beta, out_qk, out_vt, B, S, C, K, eps, 0, stream);
+}
+
+int tango_op_linear_qkv_perm(int dt, const float* x, const float* w, const float* gamma, const float* beta, float* out_qk, float* out_vt,
+                             int B, int S, int C, int K, float eps, int vt_perm, void* stream) {
+  // vt_perm = 1: out_vt with the tokens of every block of 32 in the attention kernel's fragment order (GemmParams::vt_perm; 16-bit engines, S % 32 == 0)
   // the self-attention projection of the engine: [LayerNorm](x [B*S, K]) @ Wqkv^T [3C, K] (no bias); q | k -> out_qk [B*S, 2C],
   // v -> out_vt [B][C][S] (EPI_VT).  gamma == nullptr: no LayerNorm.  Folded LN when a kernel takes it, else LN + GEMM.
   hipStream_t s = (hipStream_t)stream;
@@ -259,7 +265,7 @@ int tango_op_linear_qkv(int dt, const float* x, const float* w, const float* gam
   GemmParams p;
   p.A = xt; p.lda = K; p.W = wt; p.Kp = K; p.bias = nullptr; p.M = M; p.N = N; p.K = K; p.Cin = K;
   p.mode = GATHER_1D; p.rows_pb = M; p.Lin = M; p.Lout = M;
-  p.out = qk; p.ldo = 2 * C; p.epi = EPI_VT; p.vt = vt; p.vt_n0 = 2 * C; p.vt_S = S; p.vt_ld = S;
+  p.out = qk; p.ldo = 2 * C; p.epi = EPI_VT; p.vt = vt; p.vt_n0 = 2 * C; p.vt_S = S; p.vt_ld = S; p.vt_perm = vt_perm;
   TANGO_TRY(gemm_init());
   if (gamma) {
     TANGO_TRY(launch_fold_ln(dt, wt, K, gamma, beta, nullptr, wl, bl, ws, N, K, s));
@@ -349,6 +355,7 @@ int tango_op_qkv_stat(int dt, const float* x, const float* w, const float* gamma
                       int C, float eps, int mode, int reps, float* ms_out, void* stream) {
   // LayerNorm(x [B*S, C]) @ Wqkv^T [3C, C] (no bias): q | k -> out_qk [B*S, 2C], v -> out_vt [B][C][S].  mode 0: the activation-stationary kernel
   // (ff_fused.hip qkv_stat_kernel; C = 320), mode 1: the GEMM route the dispatcher picks (folded LayerNorm, EPI_VT).  reps / ms_out as tango_op_ff_fused.
+  // mode | 2: out_vt with the tokens of every block of 32 in the attention kernel's fragment order (vt_perm; S % 32 == 0).
   hipStream_t s = (hipStream_t)stream;
   const size_t esz = dtype_size(dt);
   Scratch sc;
@@ -368,10 +375,13 @@ int tango_op_qkv_stat(int dt, const float* x, const float* w, const float* gamma
   QKVParams q;
   q.x = xt; q.ldx = K; q.w = wl; q.ldw = K; q.b = bl; q.out = qk; q.ldo = 2 * C; q.vt = vt; q.vt_ld = S; q.vt_S = S;
   q.M = M; q.N = N; q.K = K; q.n_rm = 2 * C; q.ln = 1; q.eps = eps;
+  const int perm = (mode & 2) ? 1 : 0;
+  mode &= 1;
+  q.vt_perm = perm;
   GemmParams g;
   g.A = xt; g.lda = K; g.W = wl; g.Kp = K; g.bias = bl; g.M = M; g.N = N; g.K = K; g.Cin = K;
   g.mode = GATHER_1D; g.rows_pb = M; g.Lin = M; g.Lout = M;
-  g.out = qk; g.ldo = 2 * C; g.epi = EPI_VT; g.vt = vt; g.vt_n0 = 2 * C; g.vt_S = S; g.vt_ld = S;
+  g.out = qk; g.ldo = 2 * C; g.epi = EPI_VT; g.vt = vt; g.vt_n0 = 2 * C; g.vt_S = S; g.vt_ld = S; g.vt_perm = perm;
   g.ln_fold = 1; g.ln_eps = eps; g.wsum = ws;
   if (mode == 1 && !gemm_ln_fold_ok(dt, g)) TANGO_FAIL("op_qkv_stat: mode 1 needs a LayerNorm-folding GEMM for this shape");
   auto once = [&]() -> int { return mode == 0 ? launch_qkv_stat(dt, q, s) : launch_gemm(dt, g, s); };
@@ -539,6 +549,9 @@ int tango_op_attention_ex(int dt, const float* q, const float* k, const float* v
       p.fp8_pv = 2;
     }
   }
+  // bit 2: the rows of v arrive in the attention kernel's fragment order inside every block of 32 keys (row vt_perm_pos(s) holds key s): the V^T this
+  // op builds is then a vt_perm one and the kernel fetches K and V^T tiles by LDS-DMA (what the engine runs at its Sq > 512 self-attention sites)
+  if (flags & 4) p.vt_perm = 1;
   TANGO_TRY(launch_attention(dt, p, s));
   TANGO_TRY(to_f32(dt, ot, C, out, (int64_t)B * Sq, C, s));
   TANGO_HIP(hipStreamSynchronize(s));

@@ -49,7 +49,8 @@ struct Tuning {
   int gn_proj_stat;         // TANGO_GN_PROJ_STAT=0|1   level-0 GroupNorm -> proj_in: statistics pass + the activation-stationary kernel normalising on its way in (round 6); 0 = GroupNorm kernel + GEMM
   bool gn_fold;             // TANGO_GN_FOLD=1          GroupNorm -> proj_in as ONE GEMM with per-sample folded weights at levels 0-1 (round 6: built, within tolerance, measured +-0.0 ms per step: off)
   int attn_kdma;            // TANGO_ATTN_KDMA=0|1      unmasked 16-bit attention with Sq > 512: the K tile by LDS-DMA instead of through VGPRs (round 6)
-  int attn_vdma;            // TANGO_ATTN_VDMA=0|1      level-0 self-attention: v^T written in fragment order by qkv_stat_kernel, K AND V^T tiles by LDS-DMA (round 6)
+  int attn_vdma;            // TANGO_ATTN_VDMA=0|1|2    self-attention with Sq > 512: v^T written in fragment order by the producer, K AND V^T tiles by LDS-DMA (round 6);
+                            //                          1 = only where qkv_stat_kernel produces it (level 0), 2 = the GEMM routes' transposed epilogues as well (level 1)
   int attn_defer;           // TANGO_ATTN_DEFER=0|1     unmasked 16-bit attention: move the running softmax maximum only when a tile exceeds it by more than 2^8 (round 6); 0 = exact lazy rescale
   int attn_x8_qb;           // TANGO_ATTN_X8_QB=1|2     MX fp8 P.V attention (unet_attn_fp8 = 2): 16 query rows per wave at three waves per SIMD, or 32 at two (round 6)
   int conv_tall;            // TANGO_CONV_TALL=0|1      3x3 wide conv on the 512-pixel x 160-channel form of the tile where the halo fits (round 6: half the weight DMA per MFMA)
@@ -96,7 +97,7 @@ inline Tuning read_tuning() {
   x.attn_x8_qb = num("TANGO_ATTN_X8_QB", 2);
   x.attn_defer = num("TANGO_ATTN_DEFER", 0);
   x.attn_kdma = num("TANGO_ATTN_KDMA", 1);
-  x.attn_vdma = num("TANGO_ATTN_VDMA", 1);
+  x.attn_vdma = num("TANGO_ATTN_VDMA", 2);
   x.gn_fold = on("TANGO_GN_FOLD");
   x.ff_fused = num("TANGO_FF_FUSED", 1);
   x.qkv_stat = num("TANGO_QKV_STAT", 1);

@@ -71,3 +71,45 @@ def test_attention_deferred_rescale(lib, dtype, case, B, heads, S):
     # repeat: bit-identical
     again = _run(lib, dtype, qd, kd, vd, B, heads, S, 1)
     assert torch.equal(again, defer)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,heads,S", [(2, 5, 4096), (3, 10, 1024), (1, 5, 576)])
+def test_attention_kv_tiles_by_lds_dma(lib, dtype, B, heads, S):
+    """attn_kernel<..., KDMA, VDMA> at the op level (reference op: attention_processor.py:495-540): a V^T whose keys sit in the kernel's fragment
+    order inside every block of 32 (tango_op_attention_ex flags bit 2, AttnParams::vt_perm) is fetched by LDS-DMA like K; same arithmetic in the same
+    order as the register-staged kernel -- bitwise equal to it, and against the full fp64 reference"""
+    g = torch.Generator().manual_seed(S + heads)
+    C_ = heads * 64
+    q = q16(torch.randn(B, S, C_, generator=g), dtype)
+    k = q16(torch.randn(B, S, C_, generator=g), dtype)
+    v = q16(torch.randn(B, S, C_, generator=g) * 1.5 + 0.3, dtype)
+    s = torch.arange(S)
+    pos = (s & ~31) | ((s & 12) << 1) | ((s & 16) >> 2) | (s & 3)
+    vp = torch.empty_like(v)
+    vp[:, pos] = v                      # row pos(s) holds key s
+    qh, kh, vh = (t.view(B, S, heads, 64).transpose(1, 2).double() for t in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, -1) @ vh).transpose(1, 2).reshape(B, S, C_).float()
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    outs = {}
+    for name, kd, flags, vv in (("staged", 0, 0, v), ("kdma", 1, 0, v), ("kvdma", 1, 4, vp)):
+        out = torch.empty(B, S, C_, device="cuda")
+        qd, kdv, vd = q.cuda(), k.cuda(), vv.cuda()
+        with tuning(lib, TANGO_ATTN_KDMA=kd, TANGO_ATTN_DEFER=0):
+            rc = lib.tango_op_attention_ex(DT[dtype], p(qd), p(kdv), p(vd), None, p(out), B, heads, S, S, C.c_float(0.125), flags, None)
+        assert rc == 0, lib.tango_last_error().decode()
+        outs[name] = out.cpu()
+    err = (outs["kvdma"] - ref).abs().max().item() / ref.abs().max().item()
+    print("attention %s B=%d heads=%d S=%d: K / V^T tiles by LDS-DMA vs fp64 %.3e" % (dtype, B, heads, S, err))
+    assert err <= TOL[dtype]
+    assert torch.equal(outs["staged"], outs["kdma"])
+    assert torch.equal(outs["staged"], outs["kvdma"])
+
+
+def test_attention_vt_perm_argument_errors(lib):
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    q = torch.zeros(1, 256, 320, device="cuda")
+    out = torch.empty_like(q)
+    # a permuted V^T is only understood by the LDS-DMA form (Sq > 512): refused, never read with another kernel
+    assert lib.tango_op_attention_ex(1, p(q), p(q), p(q), None, p(out), 1, 5, 256, 256, C.c_float(0.125), 4, None) != 0
+    assert b"vt_perm" in lib.tango_last_error()
