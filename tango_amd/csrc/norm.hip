@@ -318,6 +318,110 @@ __global__ __launch_bounds__(1024) void gn_fused_small_kernel(const T* __restric
 }
 
 // ------------------------------------------------------------------------------------------
+// Slab form (round 6): the GroupNorms of UNet levels 2-3 (<= 256 rows per sample; C = 1280 / 2560, i.e. groups of 40 / 80 channels = whole 16-byte
+// vectors).  One 320-thread workgroup owns G adjacent groups of one sample -- a rows x (G cg) slab, 320 contiguous bytes (20 vectors) per row: it is read
+// ONCE as 16-byte vectors into registers (thread = (row of a 16-row pass, vector): rows / 16 vectors per thread, every load in flight before the first
+// use; its group, gamma and beta are fixed), the per-group (sum, sum of squares) go through LDS in a fixed order to a double-precision mean / variance, and the slab is normalised (+ affine, SiLU) from the registers and written once.
+// One launch, one read, one write: the two-launch path reads these tensors twice (they are 10-84 MB at B = 32: three passes through the memory side),
+// and the (sample, group)-per-workgroup kernel above fetches them as 4-byte pairs with 1024-thread workgroups (19 us per launch for a 10-MB tensor).
+// The choice depends on (rows, C, groups, dtype) only -- never on the batch -- so a sample's result does not depend on what it is batched with.
+// Reference op: torch.nn.GroupNorm of ResnetBlock2D.norm1 / norm2 and Transformer2DModel.norm (diffusers resnet.py:549-597, transformer_2d.py:255-262).
+// ------------------------------------------------------------------------------------------
+static constexpr int GSL_VPS = 20, GSL_RPP = 16, GSL_TH = GSL_VPS * GSL_RPP, GSL_MAXG = 4;   // 20 vectors per slab row x 16 rows per pass = 320 threads
+template <typename T, int NV>
+__global__ __launch_bounds__(GSL_TH, 3) void gn_slab_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int rows, int C, int groups, float eps, int act, int G, int VPG) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  __shared__ f32x2 part[GSL_TH];
+  __shared__ f32x2 part2[GSL_MAXG][GSL_RPP];
+  __shared__ float mean_s[GSL_MAXG], rstd_s[GSL_MAXG];
+  // thread -> (row of the pass r0, vector of the slab row vv): its group, gamma and beta are fixed; vector i is row r0 + 16 i
+  const int tid = threadIdx.x, r0 = tid / GSL_VPS, vv = tid - r0 * GSL_VPS, grp = vv / VPG;
+  const int b = blockIdx.y, cg = C / groups, c0 = blockIdx.x * G * cg + vv * EPV;
+  const T* xp = x + ((int64_t)b * rows + r0) * ldx + c0;
+  T* yp = y + ((int64_t)b * rows + r0) * ldy + c0;
+  const int64_t xs = (int64_t)GSL_RPP * ldx, ys = (int64_t)GSL_RPP * ldy;
+  u32x4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = *(const u32x4*)(xp + i * xs);         // rows == 16 NV (launcher): no tail
+  float ga[EPV], be[EPV];                                // (16-byte aligned: the launcher checks gamma / beta, c0 is a multiple of 4)
+#pragma unroll
+  for (int u = 0; u < EPV; u += 4) {
+    *(f32x4*)(ga + u) = *(const f32x4*)(gamma + c0 + u);
+    *(f32x4*)(be + u) = *(const f32x4*)(beta + c0 + u);
+  }
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float f[EPV];
+    unpack16<T>(v[i], f);
+#pragma unroll
+    for (int u = 0; u < EPV; ++u) { s += f[u]; q += f[u] * f[u]; }
+    __builtin_amdgcn_sched_barrier(0);                   // one vector at a time (hipcc otherwise unpacks all NV vectors at once: 8 NV registers, spills at NV = 16)
+  }
+  // per-group sums in a fixed order: the VPG vectors of a (pass row, group), then the 16 pass rows (double)
+  part[tid] = f32x2{s, q};
+  __syncthreads();
+  if (tid < G * GSL_RPP) {
+    const int k = tid / GSL_RPP, rr = tid - k * GSL_RPP;
+    float a = 0.f, c = 0.f;
+    for (int j = 0; j < VPG; ++j) { const f32x2 o = part[rr * GSL_VPS + k * VPG + j]; a += o.x; c += o.y; }
+    part2[k][rr] = f32x2{a, c};
+  }
+  __syncthreads();
+  if (tid < G) {
+    double S = 0.0, Q = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < GSL_RPP; ++rr) { S += (double)part2[tid][rr].x; Q += (double)part2[tid][rr].y; }
+    const double nn = (double)rows * cg;
+    const double mean = S / nn;
+    double var = Q / nn - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_s[tid] = (float)mean;
+    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  // (the packed vectors are made opaque here: hipcc otherwise keeps the 8 NV CONVERTED values of the statistics loop alive across the barriers
+  //  to save the second conversion -- 128 more registers at NV = 16)
+#pragma unroll
+  for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(v[i]));
+  const float mu = mean_s[grp], rstd = rstd_s[grp];
+  float sc[EPV], sh[EPV];
+#pragma unroll
+  for (int u = 0; u < EPV; ++u) { sc[u] = rstd * ga[u]; sh[u] = be[u] - mu * sc[u]; }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float f[EPV];
+    unpack16<T>(v[i], f);
+#pragma unroll
+    for (int u = 0; u < EPV; ++u) {
+      float t = f[u] * sc[u] + sh[u];
+      if (act == ACT_SILU) t = silu_f(t);
+      f[u] = t;
+    }
+    *(u32x4*)(yp + i * ys) = pack16<T>(f);
+    if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two vectors' exponentials in flight at a time, not sixteen
+  }
+}
+
+// geometry of the slab form for this shape: G groups per workgroup (20 vectors per slab row), vectors per group, vectors per thread; false = the shape does not take it
+template <typename T> static bool gn_slab_geom(int rows, int C, int groups, int& G, int& VPG, int& nv) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  const int cg = C / groups;
+  if (cg % EPV != 0 || rows % GSL_RPP != 0) return false;
+  VPG = cg / EPV;
+  if (VPG <= 0 || GSL_VPS % VPG != 0) return false;
+  G = GSL_VPS / VPG;
+  if (G > GSL_MAXG || groups % G != 0) return false;
+  nv = rows / GSL_RPP;
+  return nv == 4 || nv == 8 || nv == 16;
+}
+template <typename T, int NV> static void gn_slab_go(const GroupNormParams& p, int G, int VPG, hipStream_t s) {
+  hipLaunchKernelGGL((gn_slab_kernel<T, NV>), dim3((unsigned)(p.groups / G), (unsigned)p.B), dim3(GSL_TH), 0, s, (const T*)p.x, p.ldx, (T*)p.y, p.ldy,
+                     p.gamma, p.beta, p.rows, p.C, p.groups, p.eps, p.act, G, VPG);
+}
+
+// ------------------------------------------------------------------------------------------
 // Cooperative single-launch GroupNorm (round 4).  rocprofv3 (profiles/r4_c8_kernel_stats_b1.txt) prices a dispatch inside the
 // hipGraph at 4-5 us and the (sample, group)-per-workgroup kernel above at 16 us per call (64 workgroups, 4-byte strided loads);
 // the two-launch path reads x twice.  Here the grid of the STATISTICS pass keeps its rows in registers across a per-sample
@@ -560,6 +664,18 @@ static int gn_launch(const GroupNormParams& p, hipStream_t s) {
   // below on tensors with >= 1024 rows per sample (C=320 rows=4096 x13 0.438 -> 0.227 ms, C=640 rows=1024 x11 0.198 -> 0.162, C=1280
   // rows=1024 0.034 -> 0.023); at 256 / 64 rows that kernel's 9-13 us beat the ~10-us rendezvous, and against the two-launch path
   // (tensors > 8 MB: B >= 8) the cooperative kernel loses 5-20 % everywhere.  TANGO_GN_COOP_ALL=1 (tests) lifts the size rule.
+  // round 6: the slab form where the shape takes it (levels 2-3 of the UNet: rows <= 256, groups of whole 16-byte vectors) -- a function of the shape
+  // only, never of the batch (TANGO_GN_SLAB=0: A/B)
+  if (tuning().gn_slab) {
+    int G = 0, VPG = 0, nv = 0;
+    if ((((uintptr_t)p.gamma | (uintptr_t)p.beta) & 15) == 0 && gn_slab_geom<T>(p.rows, p.C, p.groups, G, VPG, nv)) {
+      if (nv == 4) gn_slab_go<T, 4>(p, G, VPG, s);
+      else if (nv == 8) gn_slab_go<T, 8>(p, G, VPG, s);
+      else gn_slab_go<T, 16>(p, G, VPG, s);
+      TANGO_HIP(hipGetLastError());
+      return 0;
+    }
+  }
   const bool coop_size = (size_t)p.B * p.rows * p.C * sizeof(T) <= ((size_t)8 << 20) && p.rows >= 1024;
   if (p.sync && !tuning().no_gn_coop && (coop_size || tuning().gn_coop_all)) {
     if (gn_coop_try<T, 8>(p, s)) { TANGO_HIP(hipGetLastError()); return 0; }      // (16 rows per thread: 128 VGPRs + spills at 4 waves / SIMD -- same bytes resident, not built)

@@ -65,13 +65,13 @@ def test_gn_coop_matches_torch_and_two_launch_path(lib, dtype, B, Cc, HW):
         ref = F.group_norm(x, 32, ga, be, eps)
         if act:
             ref = F.silu(ref)
-        with tuning(lib, TANGO_GN_COOP_ALL=1):
+        with tuning(lib, TANGO_GN_SLAB=0, TANGO_GN_COOP_ALL=1):
             first = gn(lib, dtype, x, ga, be, eps, act)
             err = ((first - ref).abs().max() / (ref.abs().max() + 1e-9)).item()
             assert err <= TOL[dtype], "gn_coop %s B=%d C=%d rows=%d: rel err %.3e" % (dtype, B, Cc, HW, err)
             for rep in range(10):
                 assert torch.equal(gn(lib, dtype, x, ga, be, eps, act), first), "repetition %d differs" % rep
-        with tuning(lib, TANGO_NO_GN_COOP=1):
+        with tuning(lib, TANGO_GN_SLAB=0, TANGO_NO_GN_COOP=1):
             two = gn(lib, dtype, x, ga, be, eps, act)
         # same arithmetic, different chunking of the fp32 partial sums: at most an output ulp apart
         d = ((first - two).abs().max() / (ref.abs().max() + 1e-9)).item()
@@ -83,7 +83,7 @@ def test_gn_coop_barrier_words_survive_mixed_geometries(lib):
     back at rest after every launch (a stale count would deadlock -> the kernel's timeout flag -> an error from the op)"""
     g = torch.Generator().manual_seed(7)
     cases = []
-    with tuning(lib, TANGO_GN_COOP_ALL=1):
+    with tuning(lib, TANGO_GN_SLAB=0, TANGO_GN_COOP_ALL=1):
         for B, Cc, HW in [(2, 320, 4096), (16, 1280, 256), (3, 320, 100), (2, 1280, 64)]:
             x = q(torch.randn(B, Cc, HW, generator=g), "fp16").cuda()
             ga, be = torch.randn(Cc, generator=g).cuda(), torch.randn(Cc, generator=g).cuda()
@@ -103,11 +103,11 @@ def test_gn_coop_fallback_without_rendezvous_is_bit_identical(lib, dtype, B, Cc,
     g = torch.Generator().manual_seed(11 * B + Cc + HW)
     x = q(torch.randn(B, Cc, HW, generator=g) * 1.3 - 0.2, dtype).cuda()
     ga, be = torch.randn(Cc, generator=g).cuda(), torch.randn(Cc, generator=g).cuda()
-    with tuning(lib, TANGO_GN_COOP_ALL=1):
+    with tuning(lib, TANGO_GN_SLAB=0, TANGO_GN_COOP_ALL=1):
         normal = gn(lib, dtype, x, ga, be, 1e-5, 1)
-    with tuning(lib, TANGO_GN_COOP_ALL=1, TANGO_GN_COOP_FORCE_FALLBACK=1):
+    with tuning(lib, TANGO_GN_SLAB=0, TANGO_GN_COOP_ALL=1, TANGO_GN_COOP_FORCE_FALLBACK=1):
         forced = gn(lib, dtype, x, ga, be, 1e-5, 1)
         forced2 = gn(lib, dtype, x, ga, be, 1e-5, 1)
-    with tuning(lib, TANGO_GN_COOP_ALL=1):
+    with tuning(lib, TANGO_GN_SLAB=0, TANGO_GN_COOP_ALL=1):
         again = gn(lib, dtype, x, ga, be, 1e-5, 1)
     assert torch.equal(forced, normal) and torch.equal(forced2, normal) and torch.equal(again, normal)
