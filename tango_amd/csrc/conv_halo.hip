@@ -56,7 +56,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GemmParams p, c
   unsigned char* const As = dsm;
   unsigned char* const Ws = dsm + 2 * abytes;
 
-  const int NT = p.N / BN;
+  const int NT = (p.N + BN - 1) / BN;
   int bid = blockIdx.x;
   {
     const int nblk = gridDim.x;
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GemmParams p, c
     if (rg < WRG) {
       ++my_w;
       w_src[i] = ((int64_t)(n0 + rg * 8 + lrow) * p.Kp + pc * EPV) * (int64_t)sizeof(T);
+      if constexpr (BN == 32) { if (n0 + rg * 8 + lrow >= p.N) w_src[i] = -1; }    // narrow outputs (conv_out, N = 8): rows beyond N come from the zero page
     }
   }
   my_w = __builtin_amdgcn_readfirstlane(my_w);
@@ -122,8 +123,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GemmParams p, c
 #pragma unroll
     for (int i = 0; i < WRGW; ++i) {
       const int rg = wave + 8 * i;
-      if (rg < WRG)
-        __builtin_amdgcn_global_load_lds((gptr_t)(Wb + w_src[i] + koff), (lptr_t)(Ws + st * WST + rg * 1024), 16, 0, 0);
+      if (rg < WRG) {
+        const unsigned char* src = Wb + w_src[i] + koff;
+        if constexpr (BN == 32) { if (w_src[i] < 0) src = zero_page; }
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ws + st * WST + rg * 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -318,11 +322,15 @@ bool conv_halo_ok(int dtype, const GemmParams& p) {
   if (p.mode != GATHER_2D || p.stride != 1 || p.pad != 1 || p.ups < 0 || p.ups > 1 || (p.Hin << p.ups) != p.H || (p.Win << p.ups) != p.Wd) return false;
   if (p.batch != 1 || p.splitk > 1 || p.a_act != ACT_NONE || p.epi == EPI_GEGLU || p.epi == EPI_VT) return false;
   if ((p.Cin * esz) % 128 != 0 || p.K != 9 * p.Cin || p.M % 256 != 0) return false;
-  const int bn = p.N % 160 == 0 ? 160 : 128;
-  if (p.N % bn != 0) return false;
+  // round 6: narrow outputs (the UNet's conv_out, 320 -> 8 channels) on a 256 x 32 tile of the same kernel: the activation halo is staged once per chunk instead
+  // of being gathered nine times through L2 by the 256 x 16 tile kernel (0.214 ms at 10x its byte floor); weight rows beyond N are zero-page rows
+  const bool narrow = p.N <= 32 && dtype != DT_F32 && !tuning().no_halo_narrow;
+  const int bn = narrow ? 32 : (p.N % 160 == 0 ? 160 : 128);
+  if (!narrow && p.N % bn != 0) return false;
+  if (narrow && (p.R || p.bias2 || p.e_act != ACT_NONE)) return false;
   HaloGeom g;
   if (!halo_geom(p, g)) return false;
-  const long tiles = (long)(p.M / 256) * (p.N / bn);
+  const long tiles = (long)(p.M / 256) * ((p.N + bn - 1) / bn);
   return tuning().force_big_kernels || tiles >= 256;
 }
 
@@ -337,8 +345,8 @@ static int launch_halo_cfg(const GemmParams& p, const unsigned char* zero_page, 
   // ablation hooks are a tools/ build: tools/halo_ablation.sh documents how the round-1 table was taken.)
   auto kfn = conv3x3_halo_kernel<T, BN, false, false>;
   TANGO_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(kfn), lds));
-  const int tiles = (p.M / 256) * (p.N / BN);
-  const int staged = epilogue_can_stage<T>(p) ? 1 : 0;
+  const int tiles = (p.M / 256) * ((p.N + BN - 1) / BN);
+  const int staged = (BN != 32 && epilogue_can_stage<T>(p)) ? 1 : 0;
   const int abl = 0, pp_mode = 0;
   hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(512), lds, s, p, zero_page, g.SR, g.nseg, abytes, abl, staged, pp_mode);
   TANGO_HIP(hipGetLastError());
@@ -348,6 +356,7 @@ static int launch_halo_cfg(const GemmParams& p, const unsigned char* zero_page, 
 int launch_conv_halo(int dtype, const GemmParams& p, const unsigned char* zero_page, hipStream_t s) {
   if (!zero_page) TANGO_FAIL("conv_halo: gemm_init() was not called (zero page for the LDS-DMA gather)");
   const bool bn160 = p.N % 160 == 0;
+  if (p.N <= 32 && dtype != DT_F32) return dtype == DT_F16 ? launch_halo_cfg<f16, 32>(p, zero_page, s) : launch_halo_cfg<bf16, 32>(p, zero_page, s);
   switch (dtype) {
     case DT_F32: return bn160 ? launch_halo_cfg<float, 160>(p, zero_page, s) : launch_halo_cfg<float, 128>(p, zero_page, s);
     case DT_F16: return bn160 ? launch_halo_cfg<f16, 160>(p, zero_page, s) : launch_halo_cfg<f16, 128>(p, zero_page, s);

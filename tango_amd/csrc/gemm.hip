@@ -361,6 +361,7 @@ int gemm_pick_splitk(int dtype, const GemmParams& p) {
     return 1;
   if (gemm_duo_ok(dtype, p) || linear_stream_ok(dtype, p)) return 1;
   if (small_tile_linear(p, dtype == DT_F32 ? 4 : 2)) return 1;      // one launch of 64 x 64 tiles instead (launch_tile)
+  if (p.N <= 32 && conv_halo_ok(dtype, p)) return 1;                // narrow-output convs (conv_out) on the halo kernel's 256 x 32 tile from 256 tiles on (round 6)
   {
     const int sw = conv_wide_pick_splitk(dtype, p);    // e.g. 64 tiles of 256 x 320 -> 4 splits = one workgroup per CU
     // (linears: measured at M = 4096 -- 64 tiles x 4 splits -- the wide kernel is no faster than the 4-wave tiles' split-K,

@@ -35,6 +35,7 @@ struct Tuning {
   bool no_cfg_shared;       // TANGO_NO_CFG_SHARED=1    A/B: the CFG-shared prefix of a guidance step (conv_in ... first self-attention once for both halves) off (round 5)
   bool stream_spec;         // TANGO_STREAM_SPEC=0|1     lin_stream_kernel: compile-time GEGLU + folded-LayerNorm epilogue for the level-0 projection (default on) (round 5)
   int attn_qb2_min_wgs;     // TANGO_ATTN_QB2_MIN_WGS=n attention with Sq <= 512: 32 query rows per wave once that still leaves n workgroups (default 512: level-2 self-attention at B=32 0.319 -> 0.247 ms, profiles/r4_c14_attn_qb2_ab_b32.txt); 0 = never (round 4)
+  bool no_halo_narrow;      // TANGO_NO_HALO_NARROW=1   A/B: conv_out (N <= 32) back on the 256 x 16 tile kernel instead of the halo kernel's 256 x 32 tile (round 6)
   int gn_slab;              // TANGO_GN_SLAB=0|1        GroupNorm of <= 256-row samples with vector-aligned groups (UNet levels 2-3): one workgroup keeps a rows x 4-group slab in registers -- one launch, one read, one write (round 6)
   int gn_small_mb;          // TANGO_GN_SMALL_MB=n      GroupNorm: the one-launch (sample, group)-per-workgroup kernel up to n MiB of input (default 8)
   int wide_pers;            // TANGO_WIDE_PERS=n        256 x 320 GEMM: the persistent form (next tile's first chunk prefetched behind the epilogue) from n tiles per CU on (default 2: linears of a B = 32 step 20.0 -> 19.7 ms, bit-identical results, profiles/r4_c16_wide_pers_ab_b32.txt); 0 = never (round 4)
@@ -87,6 +88,7 @@ inline Tuning read_tuning() {
   x.attn_qb2_min_wgs = num("TANGO_ATTN_QB2_MIN_WGS", 512);
   x.gn_small_mb = num("TANGO_GN_SMALL_MB", 8);
   x.gn_slab = num("TANGO_GN_SLAB", 1);
+  x.no_halo_narrow = on("TANGO_NO_HALO_NARROW");
   x.wide_pers = num("TANGO_WIDE_PERS", 2);
   x.attn_msum = num("TANGO_ATTN_MSUM", 1) != 0;
   x.duo_maxk = num("TANGO_DUO_MAXK", -1);

@@ -193,6 +193,32 @@ def test_conv2d_halo_upsampled(lib, dtype, B, Cin, Cout, H, W):
     _conv2d_halo_case(lib, dtype, B, Cin, Cout, H, W, 1)
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(16, 320, 8, 256, 16), (64, 64, 4, 64, 16), (32, 128, 32, 64, 8), (1024, 64, 24, 8, 8)])
+def test_conv2d_halo_narrow_output(lib, dtype, B, Cin, Cout, H, W):
+    """the UNet's conv_out (320 -> 8 channels; unet_2d_condition.py conv_out) and other narrow outputs on the halo kernel's 256 x 32 tile (round 6: weight
+    rows beyond N come from the zero page) -- against torch, and against the 256 x 16 / 256 x 32 tile kernels it replaces (TANGO_NO_HALO_NARROW=1)"""
+    import os
+    _conv2d_halo_case(lib, dtype, B, Cin, Cout, H, W, 0)
+    g = torch.Generator().manual_seed(Cin * Cout + H + W)
+    x = quant(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = quant(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5, dtype)
+    b = torch.randn(Cout, generator=g)
+    outs = []
+    for off in ("0", "1"):
+        os.environ["TANGO_NO_HALO_NARROW"] = off
+        lib.tango_tuning_reload()
+        try:
+            out = torch.empty(B, Cout, H, W, device="cuda")
+            check(lib, lib.tango_op_conv2d(DT[dtype], ptr(dev(x)), ptr(dev(w)), ptr(dev(b)), ptr(out), B, Cin, H, W, Cout, 1, 0, None))
+            outs.append(out.cpu())
+        finally:
+            os.environ.pop("TANGO_NO_HALO_NARROW", None)
+            lib.tango_tuning_reload()
+    d = (outs[0] - outs[1]).abs().max().item() / outs[1].abs().max().item()
+    assert d <= (4e-3 if dtype == "fp16" else 2e-2), "halo 256 x 32 tile vs the tile kernel: %.3e" % d
+
+
 def _conv2d_halo_case(lib, dtype, B, Cin, Cout, H, W, ups):
     g = torch.Generator().manual_seed(Cin * Cout + H + W)
     x = quant(torch.randn(B, Cin, H, W, generator=g), dtype)
