@@ -59,5 +59,16 @@ elif kind == "attention":
     out = torch.empty_like(q)
     for _ in range(reps):
         assert lib.tango_op_attention_ex(dt, p(q), p(k), p(v), None, p(out), B, heads, S, S, C.c_float(0.125), flags, None) == 0, lib.tango_last_error()
+elif kind == "groupnorm":
+    # groupnorm B C rows [reps [act]]   GroupNorm (+ SiLU) over [B, C, rows], 32 groups (norm.hip; TANGO_GN_SLAB=0|1 picks the form for the level 2-3 shapes)
+    B, Cc, rows = [int(v) for v in sys.argv[2:5]]
+    reps = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+    act = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+    dt = {"fp32": 0, "fp16": 1, "bf16": 2}[os.environ.get("BENCH_DTYPE", "fp16")]
+    x = torch.randn(B, Cc, rows, device="cuda")
+    ga, be = torch.randn(Cc, device="cuda"), torch.randn(Cc, device="cuda")
+    out = torch.empty_like(x)
+    for _ in range(reps):
+        assert lib.tango_op_groupnorm(dt, p(x), p(ga), p(be), p(out), B, Cc, rows, 32, C.c_float(1e-5), act, None) == 0, lib.tango_last_error()
 torch.cuda.synchronize()
 print("done")
