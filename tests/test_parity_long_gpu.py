@@ -2,7 +2,7 @@
 866M UNet -- fp16 and fp32 engines against the fp32 CPU oracle, plus fp16 vs the fp32 engine at config 3's 200 steps.
 
 The 100-step oracle costs minutes of host time, so the test only runs with TANGO_LONG_TESTS=1; the recorded outputs are
-profiles/r3_long_horizon_ladder.log and (final round-4 tree) profiles/r4_c20_long_horizon_ladder.log.  Floors are the 10-step floors of test_parity_full_gpu.py: drift must stay bounded.
+profiles/r3_long_horizon_ladder.log, (final round-4 tree) profiles/r4_c20_long_horizon_ladder.log and (final round-6 tree) profiles/r6_final7_long_horizon_ladder.log.  Floors are the 10-step floors of test_parity_full_gpu.py: drift must stay bounded.
 """
 import os
 import sys
